@@ -1,0 +1,287 @@
+/*
+ * mvk.h -- C ABI of the MI355X-native batched state / motion validity engine.
+ *
+ * Drop-in boundary for the validity hot path of the reference planner
+ * (tongtybj/motion_planning, package sampling_based_method).  Every entry point
+ * cites the reference interface it replaces (paths relative to the reference
+ * root).  Plain pointers and sizes only; no C++ / torch types cross this ABI.
+ *
+ * Conventions
+ *   - return 0 = MVK_OK, negative = error (text via mvk_last_error()).
+ *   - quaternions are (x, y, z, w), as geometry_msgs::Quaternion.
+ *   - batched state arrays are SoA: element (row r, sample i) at soa[r*ld + i]
+ *     (ld >= n is the row pitch in elements), so a wavefront reads 64
+ *     consecutive doubles per row (coalesced 512 B).
+ *   - "host" entry points take host pointers and copy; "_dev" entry points take
+ *     device pointers (HBM resident) plus a hipStream_t passed as void*.
+ *   - there is NO CPU fallback: every compute entry point fails with
+ *     MVK_ERR_NO_DEVICE when no gfx950 device / HIP runtime is usable.
+ */
+#ifndef MVK_H_
+#define MVK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVK_ABI_VERSION 1
+
+/* ---- capacities of the POD model blob --------------------------------- */
+#define MVK_MAX_SEG 16   /* chain segments: link bodies + inter-link joint bodies */
+#define MVK_MAX_ROTOR 8  /* = max links */
+#define MVK_MAX_JOINT 14 /* planned joints J */
+#define MVK_MAX_PRIM 32  /* robot collision primitives P */
+#define MVK_MAX_STATE_DIM (7 + MVK_MAX_JOINT)
+
+/* ---- error codes -------------------------------------------------------- */
+enum {
+  MVK_OK = 0,
+  MVK_ERR_INVALID_ARG = -1,
+  MVK_ERR_NO_DEVICE = -2, /* HIP runtime / gfx950 device not usable */
+  MVK_ERR_HIP = -3,       /* a HIP call failed (text in mvk_last_error) */
+  MVK_ERR_CAPACITY = -4,  /* model / scene exceeds a compiled-in capacity */
+  MVK_ERR_IO = -5,
+  MVK_ERR_NO_SOLUTION = -6
+};
+
+/* ---- enums mirroring the reference ------------------------------------- */
+/* sampling_based_method/msg/PlanningMode.msg:2-4 */
+enum { MVK_MODE_ONLY_JOINTS = 0, MVK_MODE_ONLY_BASE = 1, MVK_MODE_JOINTS_AND_BASE = 2 };
+/* sampling_based_method/msg/PlanningMode.msg:11-12 */
+enum { MVK_SE2 = 0, MVK_SE3 = 1 };
+/* squeeze_navigation/include/squeeze_navigation/planner/base_plugin.h:108-109 */
+enum { MVK_GAP_HORIZONTAL = 0, MVK_GAP_VERTICAL = 1 };
+
+enum { MVK_ROBOT_HYDRUS = 0, MVK_ROBOT_DRAGON = 1 };
+/* robot collision primitive kinds (V-spec primitive set) */
+enum { MVK_PRIM_SPHERE = 0, MVK_PRIM_CAPSULE = 1, MVK_PRIM_BOX = 2 };
+/* frame a primitive is attached to */
+enum { MVK_FRAME_SEG = 0, MVK_FRAME_GIMBAL_ROLL = 1, MVK_FRAME_GIMBAL_PITCH = 2 };
+/* batched state layouts */
+enum {
+  MVK_LAYOUT_POSE7 = 0, /* rows: px py pz qx qy qz qw j1..jJ  (7+J rows) -- the
+                           state after the unpack of motion_planning.cpp:81-129 */
+  MVK_LAYOUT_OMPL = 1   /* the OMPL state of the (mode, motion type):
+                           mode 0: j1..jJ
+                           mode 1: SE2 x y yaw | SE3 x y z qx qy qz qw
+                           mode 2: (mode-1 rows) then j1..jJ              */
+};
+
+/* ---- robot model: POD description of a serial multilink aerial robot ---- *
+ * Stands in for aerial_robot_model::RobotModel / HydrusRobotModel /
+ * Dragon::HydrusLikeRobotModel (third-party, absent from the reference tree;
+ * call sites multilink_state.cpp:107-116, motion_planning.cpp:150).
+ * Chain: F_0 = root (= link1 = baselink, motion_planning.cpp:188),
+ *        F_k = F_{k-1} * Trans(seg_t[k]) * Rot(seg_axis[k], q[seg_joint[k]]). */
+typedef struct mvk_model {
+  int32_t abi_version;
+  int32_t robot_type; /* MVK_ROBOT_* */
+  int32_t n_seg, n_joint, n_rotor, n_prim;
+  int32_t wrench_dof; /* 4: z,roll,pitch,yaw (HYDRUS)  3: z,roll,pitch (DRAGON) */
+  int32_t has_gimbal; /* rotors sit on 2-DOF (roll,pitch) gimbals solved to be vertical */
+
+  int32_t seg_axis[MVK_MAX_SEG];  /* -1 fixed, 0 x, 1 y, 2 z */
+  int32_t seg_joint[MVK_MAX_SEG]; /* planned-joint index or -1 */
+  int32_t seg_link[MVK_MAX_SEG];  /* link id (0..N-1) when the segment is a link body, else -1 */
+  double seg_t[MVK_MAX_SEG][3];   /* origin in the parent segment frame */
+  double seg_mass[MVK_MAX_SEG];
+  double seg_com[MVK_MAX_SEG][3]; /* centre of mass in the segment frame */
+
+  int32_t rotor_seg[MVK_MAX_ROTOR];
+  double rotor_pos[MVK_MAX_ROTOR][3]; /* thrust-frame origin (gimbal centre) in its segment frame */
+  double rotor_sigma[MVK_MAX_ROTOR];  /* +-1 spin direction */
+
+  double edf_offset_y; /* DRAGON dual EDFs sit at +-edf_offset_y of the gimbal-pitch frame */
+  double edf_radius;
+  double edf_max_tilt;
+
+  double gravity;
+  double m_f_rate; /* rotor drag-moment / thrust ratio (kappa) */
+  double thrust_min, thrust_max;
+  double fc_t_min_thre;  /* feasible-control torque distance threshold */
+  double fc_rp_min_thre; /* feasible-control roll/pitch distance threshold */
+  double link_length;
+
+  int32_t prim_type[MVK_MAX_PRIM];  /* MVK_PRIM_* */
+  int32_t prim_seg[MVK_MAX_PRIM];   /* segment the primitive rides on */
+  int32_t prim_frame[MVK_MAX_PRIM]; /* MVK_FRAME_* */
+  int32_t prim_rotor[MVK_MAX_PRIM]; /* rotor whose gimbal carries it (frame != SEG) */
+  double prim_pos[MVK_MAX_PRIM][3]; /* collision origin in that frame */
+  double prim_rot[MVK_MAX_PRIM][9]; /* collision origin rotation, row-major */
+  double prim_dim[MVK_MAX_PRIM][3]; /* SPHERE: r,-,- | CAPSULE: r, half length (axis = local z),- | BOX: half extents */
+
+  double joint_low[MVK_MAX_JOINT], joint_high[MVK_MAX_JOINT];
+} mvk_model;
+
+/* World obstacle.  Mirrors shape_msgs::SolidPrimitive BOX + geometry_msgs::Pose
+ * as filled by squeeze_navigation/src/planner/sampling_based_method.cpp:66-71:
+ * size = full side lengths ("dimensions"), pose = centre. */
+typedef struct mvk_box {
+  double center[3];
+  double quat[4];
+  double size[3];
+} mvk_box;
+
+/* Planner-side parameters; defaults follow motion_planning.cpp:465-532. */
+typedef struct mvk_params {
+  int32_t planning_mode; /* MVK_MODE_*  (default 0, motion_planning.cpp:487) */
+  int32_t motion_type;   /* MVK_SE2|MVK_SE3 (default 0, :488) */
+  /* -1 = reference gating (stability iff mode in {0,2} or SE3, :138-151;
+   * collision iff mode != 0, :153); 0 / 1 force the stage off / on. */
+  int32_t check_stability;
+  int32_t check_collision;
+  double eps_dist;   /* boundary band half width on min distance [m] (1e-6) */
+  double eps_margin; /* boundary band half width on stability slacks (1e-6) */
+  double pos_low[3], pos_high[3]; /* motion_planning.cpp:471-476 */
+  double joint_low[MVK_MAX_JOINT], joint_high[MVK_MAX_JOINT]; /* :478-484 */
+  double validity_resolution;        /* state_validity_check_res, :527 (0.03) */
+  int32_t valid_segment_count_factor; /* :528 (20) */
+  /* Quirk Q4 (motion_planning.cpp:252-258): mode 2 never installs resolution /
+   * factor, so OMPL defaults (0.01, 1) apply.  1 = reproduce that. */
+  int32_t mode2_ompl_defaults;
+  double joint_subspace_weight; /* :255 (0.001) */
+} mvk_params;
+
+typedef struct mvk_result {
+  uint8_t valid;
+  uint8_t band; /* within eps of a constraint boundary, or non-finite input */
+  uint8_t stable;
+  uint8_t collision;
+  double min_dist; /* signed separation to the obstacle set (+inf when none / skipped) */
+  double margin;   /* min stability slack (>= 0 <=> stabilityCheck() true) */
+} mvk_result;
+
+/* Optional per-sample detail outputs (NULL = not wanted).  Rows as documented. */
+typedef struct mvk_detail_out {
+  double* fc_t_min;           /* [n] */
+  double* fc_rp_min;          /* [n] */
+  double* thrust;             /* [n_rotor][ld] static thrust lambda (getStaticThrust) */
+  double* rp_position_margin; /* [n] legacy margin logged as minimum_var (motion_planning.cpp:615-620) */
+  double* cog;                /* [3][ld] world CoG position (multilink_state.cpp:115-117) */
+  double* gimbal;             /* [2*n_rotor][ld] solved (roll,pitch) per gimbal; DRAGON only */
+} mvk_detail_out;
+
+/* Reduction over the most recent batch of a ctx (motion_planning.cpp:546-642
+ * keeps the same running extrema over a path). */
+typedef struct mvk_stats {
+  uint64_t n, valid_count, band_count;
+  double min_dist;
+  int64_t min_dist_index;
+  double min_margin;
+  int64_t min_margin_index;
+  double max_thrust; /* max over samples of max_i lambda_i (max_force_, :623-627) */
+  int64_t max_thrust_index;
+  double min_thrust; /* min over samples of min_i lambda_i */
+  int64_t min_thrust_index;
+  double min_rp_position_margin; /* min_var_ (:615-620) */
+  int64_t min_rp_position_margin_index;
+} mvk_stats;
+
+typedef struct mvk_ctx mvk_ctx;
+
+/* ---- library -------------------------------------------------------------- */
+int mvk_abi_version(void);
+size_t mvk_model_sizeof(void);
+size_t mvk_params_sizeof(void);
+const char* mvk_last_error(void);
+/* number of usable gfx950 devices (0 when none / no runtime) */
+int mvk_device_count(void);
+
+/* ---- model / scene / params factories (host only, no device needed) ------ */
+/* Parametric N-link HYDRUS (planar yaw chain) and DRAGON (pitch+yaw joints,
+ * gimballed dual rotors).  The reference loads these from URDFs that live in
+ * the hydrus / dragon packages (hydrus_passing_planning.launch:19-22,
+ * dragon_passing_planning.launch:21); geometry hints: hydrus.yaml:31-33,
+ * quad.urdf.xacro:7-12.  Numbers are frozen in DESIGN.md section 3. */
+int mvk_model_hydrus(int n_links, mvk_model* out);
+int mvk_model_dragon(int n_links, mvk_model* out);
+/* defaults of motion_planning.cpp:465-532 with the model's joint limits */
+int mvk_params_default(const mvk_model* model, int planning_mode, int motion_type, mvk_params* out);
+/* The gap worlds of SamplingBasedMethod::setCollisionWorld
+ * (squeeze_navigation/src/planner/sampling_based_method.cpp:76-113 / :114-198).
+ * Returns the number of boxes written (<= cap), negative on error. */
+int mvk_scene_horizontal_gap(double gap_left_x, double gap_y_offset, double gap_left_width,
+                             double gap_right_width, mvk_box* out, int cap);
+int mvk_scene_vertical_gap(double gap_x_width, double gap_y_width, double gap_height,
+                           int planning_walls, double ceiling_offset, double side_wall_width,
+                           mvk_box* out, int cap);
+
+/* ---- context --------------------------------------------------------------- */
+/* Replaces MotionPlanning's ownership of robot_model_ptr_ + planning_scene_
+ * (motion_planning.h:128,133; planInit motion_planning.cpp:354-361). */
+mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, size_t n_boxes,
+                    const mvk_params* params, int device);
+void mvk_destroy(mvk_ctx* ctx);
+/* MotionPlanning::setScene (motion_planning.cpp:167-175): replaces the obstacle set. */
+int mvk_set_scene(mvk_ctx* ctx, const mvk_box* boxes, size_t n_boxes);
+int mvk_set_params(mvk_ctx* ctx, const mvk_params* params);
+int mvk_get_params(const mvk_ctx* ctx, mvk_params* out);
+/* rows of a state in the given layout for the ctx's (mode, motion type) */
+int mvk_state_dim(const mvk_ctx* ctx, int layout);
+
+/* ---- the predicate --------------------------------------------------------- */
+/* MotionPlanning::isStateValid (motion_planning.cpp:76-164) for ONE state in
+ * MVK_LAYOUT_OMPL.  Runs the same device kernel on a batch of one. */
+int mvk_is_valid(mvk_ctx* ctx, const double* state, mvk_result* out);
+
+/* Batched predicate (north star: isValid(states[N])).  flags[i] = 1 valid.
+ * min_dist / margin / band may be NULL; asking for any of them selects the
+ * full evaluation (no early exit), otherwise the flag-only fast path runs. */
+int mvk_is_valid_batch(mvk_ctx* ctx, const double* soa, size_t n, size_t ld, int layout,
+                       uint8_t* flags, double* min_dist, double* margin, uint8_t* band);
+int mvk_is_valid_batch_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout,
+                           uint8_t* d_flags, double* d_min_dist, double* d_margin,
+                           uint8_t* d_band, void* stream);
+/* same, with the validity flags packed one bit per sample (bit i%64 of word
+ * i/64, little endian) -- the form that is all-gathered across GPUs. */
+int mvk_is_valid_mask_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout,
+                          uint64_t* d_mask, void* stream);
+
+/* Full evaluation with per-sample model quantities (what MultilinkState /
+ * addState expose: multilink_state.cpp:98-137, motion_planning.cpp:546-642). */
+int mvk_eval_batch(mvk_ctx* ctx, const double* soa, size_t n, size_t ld, int layout,
+                   uint8_t* flags, double* min_dist, double* margin, uint8_t* band,
+                   const mvk_detail_out* detail);
+int mvk_eval_batch_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout,
+                       uint8_t* d_flags, double* d_min_dist, double* d_margin, uint8_t* d_band,
+                       const mvk_detail_out* d_detail, void* stream);
+/* extrema over the last *_batch / eval call on this ctx (device reduction) */
+int mvk_reduce_stats(mvk_ctx* ctx, mvk_stats* out);
+
+/* ---- motion validation ------------------------------------------------------- */
+/* ompl::base::DiscreteMotionValidator::checkMotion bound at
+ * motion_planning.cpp:238,249 (and the densification loop :434-444).
+ * s1/s2 are SoA batches in MVK_LAYOUT_OMPL.  nd[e] (or the scalar nd_uniform
+ * when nd == NULL) is validSegmentCount; states j/nd, j = 1..nd are tested
+ * (s1 is assumed valid, as OMPL does).  ok[e] = 1 when all are valid;
+ * first_invalid[e] = smallest invalid j, or nd+1 when none (so the
+ * lastValid fraction of the 3-argument checkMotion is (first_invalid-1)/nd). */
+int mvk_check_motion_batch(mvk_ctx* ctx, const double* s1_soa, const double* s2_soa,
+                           size_t n_edges, size_t ld, const int32_t* nd, int32_t nd_uniform,
+                           uint8_t* ok, int32_t* first_invalid);
+int mvk_check_motion_batch_dev(mvk_ctx* ctx, const double* d_s1, const double* d_s2,
+                               size_t n_edges, size_t ld, const int32_t* d_nd, int32_t nd_uniform,
+                               uint8_t* d_ok, int32_t* d_first_invalid, void* stream);
+
+/* OMPL state-space arithmetic (host, scalar, no device needed; used by the
+ * adapter and the planner): StateSpace::distance / interpolate /
+ * validSegmentCount / getMaximumExtent of the space planInit builds for
+ * (planning_mode, motion_type) (motion_planning.cpp:192-258).  States are in
+ * MVK_LAYOUT_OMPL; n_joint = J. */
+int mvk_space_dim(const mvk_params* p, int n_joint);
+double mvk_space_distance(const mvk_params* p, int n_joint, const double* s1, const double* s2);
+int mvk_space_interpolate(const mvk_params* p, int n_joint, const double* s1, const double* s2,
+                          double t, double* out);
+int mvk_space_valid_segment_count(const mvk_params* p, int n_joint, const double* s1,
+                                  const double* s2);
+double mvk_space_max_extent(const mvk_params* p, int n_joint);
+/* the unpack of motion_planning.cpp:81-129: OMPL state -> px py pz qx qy qz qw j1..jJ */
+int mvk_space_unpack(const mvk_params* p, int n_joint, const double* s, double* pose7j);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVK_H_ */

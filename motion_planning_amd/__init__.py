@@ -1,0 +1,13 @@
+"""motion_planning_amd -- MI355X-native batched state / motion validity engine.
+
+The product is the C-ABI library built from motion_planning_amd/csrc
+(include/mvk.h); this package is the ctypes plumbing used by tests and bench.py.
+"""
+from . import _abi as abi
+from ._abi import (LAYOUT_OMPL, LAYOUT_POSE7, MODE_JOINTS_AND_BASE, MODE_ONLY_BASE, MODE_ONLY_JOINTS, SE2, SE3)
+from .engine import (Engine, MvkError, Space, boxes_from_array, default_params, horizontal_gap_scene, make_model,
+                     vertical_gap_scene)
+
+__all__ = ["abi", "Engine", "MvkError", "Space", "make_model", "default_params", "horizontal_gap_scene",
+           "vertical_gap_scene", "boxes_from_array", "LAYOUT_OMPL", "LAYOUT_POSE7", "MODE_ONLY_JOINTS",
+           "MODE_ONLY_BASE", "MODE_JOINTS_AND_BASE", "SE2", "SE3"]

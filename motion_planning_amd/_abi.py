@@ -1,0 +1,140 @@
+"""ctypes mirror of include/mvk.h (structs, enums, prototypes).
+
+Plumbing only: no arithmetic happens in Python.  The struct layouts are checked
+against the library's own sizeof() at load time.
+"""
+import ctypes as C
+import os
+
+MAX_SEG, MAX_ROTOR, MAX_JOINT, MAX_PRIM = 16, 8, 14, 32
+MAX_STATE_DIM = 7 + MAX_JOINT
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_IO, ERR_NO_SOLUTION = 0, -1, -2, -3, -4, -5, -6
+MODE_ONLY_JOINTS, MODE_ONLY_BASE, MODE_JOINTS_AND_BASE = 0, 1, 2
+SE2, SE3 = 0, 1
+ROBOT_HYDRUS, ROBOT_DRAGON = 0, 1
+PRIM_SPHERE, PRIM_CAPSULE, PRIM_BOX = 0, 1, 2
+FRAME_SEG, FRAME_GIMBAL_ROLL, FRAME_GIMBAL_PITCH = 0, 1, 2
+LAYOUT_POSE7, LAYOUT_OMPL = 0, 1
+
+d, i32 = C.c_double, C.c_int32
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("abi_version", i32), ("robot_type", i32),
+        ("n_seg", i32), ("n_joint", i32), ("n_rotor", i32), ("n_prim", i32),
+        ("wrench_dof", i32), ("has_gimbal", i32),
+        ("seg_axis", i32 * MAX_SEG), ("seg_joint", i32 * MAX_SEG), ("seg_link", i32 * MAX_SEG),
+        ("seg_t", (d * 3) * MAX_SEG), ("seg_mass", d * MAX_SEG), ("seg_com", (d * 3) * MAX_SEG),
+        ("rotor_seg", i32 * MAX_ROTOR), ("rotor_pos", (d * 3) * MAX_ROTOR), ("rotor_sigma", d * MAX_ROTOR),
+        ("edf_offset_y", d), ("edf_radius", d), ("edf_max_tilt", d),
+        ("gravity", d), ("m_f_rate", d), ("thrust_min", d), ("thrust_max", d),
+        ("fc_t_min_thre", d), ("fc_rp_min_thre", d), ("link_length", d),
+        ("prim_type", i32 * MAX_PRIM), ("prim_seg", i32 * MAX_PRIM), ("prim_frame", i32 * MAX_PRIM),
+        ("prim_rotor", i32 * MAX_PRIM),
+        ("prim_pos", (d * 3) * MAX_PRIM), ("prim_rot", (d * 9) * MAX_PRIM), ("prim_dim", (d * 3) * MAX_PRIM),
+        ("joint_low", d * MAX_JOINT), ("joint_high", d * MAX_JOINT),
+    ]
+
+
+class Box(C.Structure):
+    _fields_ = [("center", d * 3), ("quat", d * 4), ("size", d * 3)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("planning_mode", i32), ("motion_type", i32), ("check_stability", i32), ("check_collision", i32),
+        ("eps_dist", d), ("eps_margin", d),
+        ("pos_low", d * 3), ("pos_high", d * 3),
+        ("joint_low", d * MAX_JOINT), ("joint_high", d * MAX_JOINT),
+        ("validity_resolution", d), ("valid_segment_count_factor", i32), ("mode2_ompl_defaults", i32),
+        ("joint_subspace_weight", d),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [("valid", C.c_uint8), ("band", C.c_uint8), ("stable", C.c_uint8), ("collision", C.c_uint8),
+                ("min_dist", d), ("margin", d)]
+
+
+class DetailOut(C.Structure):
+    _fields_ = [("fc_t_min", C.c_void_p), ("fc_rp_min", C.c_void_p), ("thrust", C.c_void_p),
+                ("rp_position_margin", C.c_void_p), ("cog", C.c_void_p), ("gimbal", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("valid_count", C.c_uint64), ("band_count", C.c_uint64),
+                ("min_dist", d), ("min_dist_index", C.c_int64),
+                ("min_margin", d), ("min_margin_index", C.c_int64),
+                ("max_thrust", d), ("max_thrust_index", C.c_int64),
+                ("min_thrust", d), ("min_thrust_index", C.c_int64),
+                ("min_rp_position_margin", d), ("min_rp_position_margin_index", C.c_int64)]
+
+
+vp, sz, ip = C.c_void_p, C.c_size_t, C.c_int
+PM, PP, PB = C.POINTER(Model), C.POINTER(Params), C.POINTER(Box)
+
+# every symbol include/mvk.h declares: name -> (restype, argtypes)
+PROTOTYPES = {
+    "mvk_abi_version": (ip, []),
+    "mvk_model_sizeof": (sz, []),
+    "mvk_params_sizeof": (sz, []),
+    "mvk_last_error": (C.c_char_p, []),
+    "mvk_device_count": (ip, []),
+    "mvk_model_hydrus": (ip, [ip, PM]),
+    "mvk_model_dragon": (ip, [ip, PM]),
+    "mvk_params_default": (ip, [PM, ip, ip, PP]),
+    "mvk_scene_horizontal_gap": (ip, [d, d, d, d, PB, ip]),
+    "mvk_scene_vertical_gap": (ip, [d, d, d, ip, d, d, PB, ip]),
+    "mvk_create": (vp, [PM, PB, sz, PP, ip]),
+    "mvk_destroy": (None, [vp]),
+    "mvk_set_scene": (ip, [vp, PB, sz]),
+    "mvk_set_params": (ip, [vp, PP]),
+    "mvk_get_params": (ip, [vp, PP]),
+    "mvk_state_dim": (ip, [vp, ip]),
+    "mvk_is_valid": (ip, [vp, vp, C.POINTER(Result)]),
+    "mvk_is_valid_batch": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp]),
+    "mvk_is_valid_batch_dev": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, vp]),
+    "mvk_is_valid_mask_dev": (ip, [vp, vp, sz, sz, ip, vp, vp]),
+    "mvk_eval_batch": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, C.POINTER(DetailOut)]),
+    "mvk_eval_batch_dev": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, C.POINTER(DetailOut), vp]),
+    "mvk_reduce_stats": (ip, [vp, C.POINTER(Stats)]),
+    "mvk_check_motion_batch": (ip, [vp, vp, vp, sz, sz, vp, i32, vp, vp]),
+    "mvk_check_motion_batch_dev": (ip, [vp, vp, vp, sz, sz, vp, i32, vp, vp, vp]),
+    "mvk_space_dim": (ip, [PP, ip]),
+    "mvk_space_distance": (d, [PP, ip, vp, vp]),
+    "mvk_space_interpolate": (ip, [PP, ip, vp, vp, d, vp]),
+    "mvk_space_valid_segment_count": (ip, [PP, ip, vp, vp]),
+    "mvk_space_max_extent": (d, [PP, ip]),
+    "mvk_space_unpack": (ip, [PP, ip, vp, vp]),
+}
+
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmvk.so")
+
+
+def load():
+    """Load libmvk.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no Python / CPU fallback for the validity kernels)")
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mvk_abi_version() != 1:
+        raise RuntimeError("libmvk.so ABI version mismatch")
+    if lib.mvk_model_sizeof() != C.sizeof(Model) or lib.mvk_params_sizeof() != C.sizeof(Params):
+        raise RuntimeError("ctypes struct layout differs from the C ABI")
+    _LIB = lib
+    return lib

@@ -1,0 +1,590 @@
+// mvk_capi.cpp -- the C ABI of include/mvk.h: context ownership (device copies of
+// the model blob and the obstacle set, staging buffers, a private stream) and the
+// entry points that marshal a call into one kernel launch.
+//
+// There is deliberately no CPU evaluation path in this library: when no HIP
+// device is usable every compute entry point returns MVK_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mvk_internal.h"
+
+namespace mvk {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+namespace {
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return fail(MVK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                  __FILE__, __LINE__);                                                 \
+  } while (0)
+
+struct Buf {  // grow-only device buffer
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return MVK_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+    return MVK_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+void quat_to_rows(const double q[4], double R[9]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double s = 2.0 / (x * x + y * y + z * z + w * w);
+  R[0] = 1.0 - s * (y * y + z * z); R[1] = s * (x * y - w * z);       R[2] = s * (x * z + w * y);
+  R[3] = s * (x * y + w * z);       R[4] = 1.0 - s * (x * x + z * z); R[5] = s * (y * z - w * x);
+  R[6] = s * (x * z - w * y);       R[7] = s * (y * z + w * x);       R[8] = 1.0 - s * (x * x + y * y);
+}
+
+}  // namespace
+}  // namespace mvk
+
+using namespace mvk;
+
+struct mvk_ctx {
+  int device = 0;
+  mvk_model model{};
+  mvk_params params{};
+  DevExtras extras{};
+  mvk_model* d_model = nullptr;
+  DevExtras* d_extras = nullptr;
+  Buf obs;
+  int n_obs = 0;
+  hipStream_t stream = nullptr;
+  // staging for the host-pointer entry points
+  Buf in_a, in_b, flags, band, mind, margin, det[6], nd, ok, first, edge_off;
+  // statistics of the last FULL batch
+  Buf partial, stats_out;
+  uint64_t last_blocks = 0, last_n = 0;
+  bool stats_valid = false;
+};
+
+namespace {
+
+int check_model_shape(const mvk_model* m) {
+  if (m->abi_version != MVK_ABI_VERSION) return fail(MVK_ERR_INVALID_ARG, "model abi_version %d != %d", m->abi_version, MVK_ABI_VERSION);
+  if (!kernel_supported(m->robot_type, m->n_rotor))
+    return fail(MVK_ERR_CAPACITY, "no kernel instantiated for robot_type %d with %d links", m->robot_type, m->n_rotor);
+  const bool dragon = m->robot_type == MVK_ROBOT_DRAGON;
+  const int NL = m->n_rotor;
+  const int ns = dragon ? 2 * NL - 1 : NL, nj = dragon ? 2 * (NL - 1) : NL - 1;
+  if (m->n_seg != ns || m->n_joint != nj || m->has_gimbal != (dragon ? 1 : 0) || m->wrench_dof != (dragon ? 3 : 4))
+    return fail(MVK_ERR_INVALID_ARG, "model does not have the chain shape of its robot_type");
+  for (int k = 1; k < ns; ++k) {
+    const int axis = dragon ? ((k & 1) ? 1 : 2) : 2;
+    if (m->seg_axis[k] != axis || m->seg_joint[k] != k - 1)
+      return fail(MVK_ERR_INVALID_ARG, "segment %d: joint axis / index differ from the compiled chain shape", k);
+  }
+  for (int i = 0; i < NL; ++i)
+    if (m->rotor_seg[i] != (dragon ? 2 * i : i)) return fail(MVK_ERR_INVALID_ARG, "rotor %d rides on an unexpected segment", i);
+  if (m->n_prim < 0 || m->n_prim > MVK_MAX_PRIM) return fail(MVK_ERR_CAPACITY, "too many collision primitives");
+  for (int q = 0; q < m->n_prim; ++q) {
+    if (m->prim_type[q] < MVK_PRIM_SPHERE || m->prim_type[q] > MVK_PRIM_BOX) return fail(MVK_ERR_INVALID_ARG, "primitive %d: unknown kind", q);
+    if (m->prim_seg[q] < 0 || m->prim_seg[q] >= ns) return fail(MVK_ERR_INVALID_ARG, "primitive %d: bad segment", q);
+    if (m->prim_frame[q] != MVK_FRAME_SEG) {
+      if (!dragon) return fail(MVK_ERR_INVALID_ARG, "primitive %d: gimbal frame on a robot without gimbals", q);
+      const int i = m->prim_rotor[q];
+      if (i < 0 || i >= NL || m->rotor_seg[i] != m->prim_seg[q]) return fail(MVK_ERR_INVALID_ARG, "primitive %d: gimbal / segment mismatch", q);
+    }
+  }
+  return MVK_OK;
+}
+
+void derive_extras(const mvk_model* m, DevExtras* x) {
+  std::memset(x, 0, sizeof(*x));
+  x->tan_edf_max_tilt = std::tan(m->edf_max_tilt);
+  int at = 0;
+  for (int k = 0; k < m->n_seg; ++k) {
+    x->seg_prim_begin[k] = at;
+    for (int q = 0; q < m->n_prim; ++q)
+      if (m->prim_seg[q] == k) x->prim_order[at++] = q;
+  }
+  for (int k = m->n_seg; k <= MVK_MAX_SEG; ++k) x->seg_prim_begin[k] = at;
+  for (int q = 0; q < m->n_prim; ++q) {
+    const double* d = m->prim_dim[q];
+    switch (m->prim_type[q]) {
+      case MVK_PRIM_SPHERE: x->prim_bound[q] = d[0]; x->prim_inner[q] = d[0]; break;
+      case MVK_PRIM_CAPSULE: x->prim_bound[q] = d[0] + d[1]; x->prim_inner[q] = d[0]; break;
+      default:
+        x->prim_bound[q] = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        x->prim_inner[q] = std::fmin(d[0], std::fmin(d[1], d[2]));
+    }
+  }
+}
+
+int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
+  if (n > 65535) return fail(MVK_ERR_CAPACITY, "at most 65535 obstacles (16-bit candidate ids)");
+  if (n && !boxes) return fail(MVK_ERR_INVALID_ARG, "null obstacle array");
+  std::vector<DevObs> host(n);
+  for (size_t i = 0; i < n; ++i) {
+    DevObs& o = host[i];
+    for (int k = 0; k < 3; ++k) {
+      o.c[k] = boxes[i].center[k];
+      o.h[k] = 0.5 * boxes[i].size[k];
+      if (!(boxes[i].size[k] >= 0.0)) return fail(MVK_ERR_INVALID_ARG, "obstacle %zu: negative or NaN size", i);
+    }
+    quat_to_rows(boxes[i].quat, o.R);
+    for (int k = 0; k < 9; ++k)
+      if (!std::isfinite(o.R[k])) return fail(MVK_ERR_INVALID_ARG, "obstacle %zu: invalid quaternion", i);
+    o.bound = std::sqrt(o.h[0] * o.h[0] + o.h[1] * o.h[1] + o.h[2] * o.h[2]);
+  }
+  if (int rc = c->obs.reserve(sizeof(DevObs) * (n ? n : 1))) return rc;
+  if (n) HIP_TRY(hipMemcpy(c->obs.p, host.data(), sizeof(DevObs) * n, hipMemcpyHostToDevice));
+  c->n_obs = static_cast<int>(n);
+  return MVK_OK;
+}
+
+int check_params(const mvk_model* m, const mvk_params* p) {
+  if (p->planning_mode < 0 || p->planning_mode > 2) return fail(MVK_ERR_INVALID_ARG, "planning_mode must be 0..2");
+  if (p->motion_type < 0 || p->motion_type > 1) return fail(MVK_ERR_INVALID_ARG, "motion_type must be 0 (SE2) or 1 (SE3)");
+  if (!(p->eps_dist >= 0.0) || !(p->eps_margin >= 0.0)) return fail(MVK_ERR_INVALID_ARG, "negative band width");
+  (void)m;
+  return MVK_OK;
+}
+
+int layout_rows(const mvk_ctx* c, int layout) {
+  if (layout == MVK_LAYOUT_POSE7) return 7 + c->model.n_joint;
+  if (layout == MVK_LAYOUT_OMPL) return space_dim(&c->params, c->model.n_joint);
+  return fail(MVK_ERR_INVALID_ARG, "unknown layout %d", layout);
+}
+
+void base_args(const mvk_ctx* c, EvalArgs& a) {
+  std::memset(&a, 0, sizeof(a));
+  const mvk_params& p = c->params;
+  a.planning_mode = p.planning_mode;
+  a.motion_type = p.motion_type;
+  // gating of motion_planning.cpp:138-151 (stability) and :153 (collision)
+  a.do_stab = p.check_stability < 0 ? (p.planning_mode != MVK_MODE_ONLY_BASE || p.motion_type == MVK_SE3)
+                                    : (p.check_stability != 0);
+  a.do_coll = p.check_collision < 0 ? (p.planning_mode != MVK_MODE_ONLY_JOINTS) : (p.check_collision != 0);
+  a.eps_dist = p.eps_dist;
+  a.eps_margin = p.eps_margin;
+  a.model = c->d_model;
+  a.extras = c->d_extras;
+  a.obs = static_cast<const DevObs*>(c->obs.p);
+  a.n_obs = c->n_obs;
+  a.nd_uniform = 1;
+}
+
+int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
+                 uint64_t* d_mask, double* d_min_dist, double* d_margin, uint8_t* d_band,
+                 const mvk_detail_out* det, bool force_full, hipStream_t s) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  if (n == 0) return MVK_OK;
+  if (!d_soa || ld < n) return fail(MVK_ERR_INVALID_ARG, "bad state array (null, or ld < n)");
+  const int rows = layout_rows(c, layout);
+  if (rows < 0) return rows;
+  HIP_TRY(hipSetDevice(c->device));
+  EvalArgs a;
+  base_args(c, a);
+  a.soa = d_soa;
+  a.n = n;
+  a.ld = ld;
+  a.layout = layout;
+  a.flags = d_flags;
+  a.mask = d_mask;
+  a.min_dist = d_min_dist;
+  a.margin = d_margin;
+  a.band = d_band;
+  bool want_detail = false;
+  if (det) {
+    a.fc_t_min = det->fc_t_min; a.fc_rp_min = det->fc_rp_min; a.thrust = det->thrust;
+    a.rp_margin = det->rp_position_margin; a.cog = det->cog; a.gimbal = det->gimbal;
+    want_detail = det->fc_t_min || det->fc_rp_min || det->thrust || det->rp_position_margin || det->cog || det->gimbal;
+  }
+  a.full = (force_full || d_min_dist || d_margin || d_band || want_detail) ? 1 : 0;
+  c->stats_valid = false;
+  if (a.full) {
+    const uint64_t blocks = (n + kBlock - 1) / kBlock;
+    if (int rc = c->partial.reserve(blocks * sizeof(StatsPartial))) return rc;
+    a.stats_partial = c->partial.p;
+    c->last_blocks = blocks;
+    c->last_n = n;
+  }
+  const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s);
+  if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+  c->stats_valid = a.full != 0;
+  return MVK_OK;
+}
+
+// copy a [rows][n] SoA block with row pitch ld (elements) between host and device
+int copy_rows(void* dst, size_t dst_ld, const void* src, size_t src_ld, size_t elem, size_t n, size_t rows,
+              hipMemcpyKind kind, hipStream_t s) {
+  HIP_TRY(hipMemcpy2DAsync(dst, dst_ld * elem, src, src_ld * elem, n * elem, rows, kind, s));
+  return MVK_OK;
+}
+
+size_t round_up(size_t n, size_t m) { return (n + m - 1) / m * m; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" int mvk_abi_version(void) { return MVK_ABI_VERSION; }
+extern "C" size_t mvk_model_sizeof(void) { return sizeof(mvk_model); }
+extern "C" size_t mvk_params_sizeof(void) { return sizeof(mvk_params); }
+extern "C" const char* mvk_last_error(void) { return g_err; }
+
+extern "C" int mvk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int usable = 0;
+  for (int d = 0; d < n; ++d) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
+  }
+  return usable;
+}
+
+extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, size_t n_boxes,
+                               const mvk_params* params, int device) {
+  if (!model || !params) {
+    fail(MVK_ERR_INVALID_ARG, "mvk_create: null model or params");
+    return nullptr;
+  }
+  if (check_model_shape(model) != MVK_OK || check_params(model, params) != MVK_OK) return nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    fail(MVK_ERR_NO_DEVICE, "mvk_create: no HIP device available (this library has no CPU path)");
+    return nullptr;
+  }
+  if (device < 0 || device >= count) {
+    fail(MVK_ERR_INVALID_ARG, "mvk_create: device %d out of range (0..%d)", device, count - 1);
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    fail(MVK_ERR_NO_DEVICE, "mvk_create: device %d is not gfx950 (kernels are built for MI355X only)", device);
+    return nullptr;
+  }
+  mvk_ctx* c = new (std::nothrow) mvk_ctx();
+  if (!c) {
+    fail(MVK_ERR_CAPACITY, "mvk_create: out of host memory");
+    return nullptr;
+  }
+  c->device = device;
+  c->model = *model;
+  c->params = *params;
+  derive_extras(model, &c->extras);
+  auto bail = [&](const char* what, hipError_t e) -> mvk_ctx* {
+    fail(MVK_ERR_HIP, "mvk_create: %s: %s", what, hipGetErrorString(e));
+    mvk_destroy(c);
+    return nullptr;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_model), sizeof(mvk_model))) != hipSuccess) return bail("hipMalloc(model)", e);
+  if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_extras), sizeof(DevExtras))) != hipSuccess) return bail("hipMalloc(extras)", e);
+  if ((e = hipMemcpy(c->d_model, &c->model, sizeof(mvk_model), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload model", e);
+  if ((e = hipMemcpy(c->d_extras, &c->extras, sizeof(DevExtras), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload extras", e);
+  if (upload_scene(c, boxes, n_boxes) != MVK_OK) {
+    mvk_destroy(c);
+    return nullptr;
+  }
+  return c;
+}
+
+extern "C" void mvk_destroy(mvk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamDestroy(c->stream);
+  }
+  if (c->d_model) (void)hipFree(c->d_model);
+  if (c->d_extras) (void)hipFree(c->d_extras);
+  Buf* all[] = {&c->obs, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
+                &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
+                &c->partial, &c->stats_out};
+  for (Buf* b : all) b->release();
+  delete c;
+}
+
+extern "C" int mvk_set_scene(mvk_ctx* c, const mvk_box* boxes, size_t n_boxes) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return upload_scene(c, boxes, n_boxes);
+}
+
+extern "C" int mvk_set_params(mvk_ctx* c, const mvk_params* p) {
+  if (!c || !p) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  if (int rc = check_params(&c->model, p)) return rc;
+  c->params = *p;
+  return MVK_OK;
+}
+
+extern "C" int mvk_get_params(const mvk_ctx* c, mvk_params* out) {
+  if (!c || !out) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  *out = c->params;
+  return MVK_OK;
+}
+
+extern "C" int mvk_state_dim(const mvk_ctx* c, int layout) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  return layout_rows(c, layout);
+}
+
+// ---- batched predicate --------------------------------------------------------
+extern "C" int mvk_is_valid_batch_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout,
+                                      uint8_t* d_flags, double* d_min_dist, double* d_margin, uint8_t* d_band,
+                                      void* stream) {
+  return run_eval_dev(c, d_soa, n, ld, layout, d_flags, nullptr, d_min_dist, d_margin, d_band, nullptr, false,
+                      static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mvk_is_valid_mask_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout,
+                                     uint64_t* d_mask, void* stream) {
+  if (!d_mask) return fail(MVK_ERR_INVALID_ARG, "null mask");
+  return run_eval_dev(c, d_soa, n, ld, layout, nullptr, d_mask, nullptr, nullptr, nullptr, nullptr, false,
+                      static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mvk_eval_batch_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout,
+                                  uint8_t* d_flags, double* d_min_dist, double* d_margin, uint8_t* d_band,
+                                  const mvk_detail_out* d_detail, void* stream) {
+  return run_eval_dev(c, d_soa, n, ld, layout, d_flags, nullptr, d_min_dist, d_margin, d_band, d_detail, true,
+                      static_cast<hipStream_t>(stream));
+}
+
+namespace {
+int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, uint8_t* flags, double* min_dist,
+              double* margin, uint8_t* band, const mvk_detail_out* det, bool force_full) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  if (n == 0) return MVK_OK;
+  if (!soa || ld < n) return fail(MVK_ERR_INVALID_ARG, "bad state array (null, or ld < n)");
+  const int rows = layout_rows(c, layout);
+  if (rows < 0) return rows;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t dld = round_up(n, 64);
+  const int NL = c->model.n_rotor;
+  if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
+  if (int rc = copy_rows(c->in_a.p, dld, soa, ld, sizeof(double), n, rows, hipMemcpyHostToDevice, s)) return rc;
+  if (flags) if (int rc = c->flags.reserve(dld)) return rc;
+  if (band) if (int rc = c->band.reserve(dld)) return rc;
+  if (min_dist) if (int rc = c->mind.reserve(dld * sizeof(double))) return rc;
+  if (margin) if (int rc = c->margin.reserve(dld * sizeof(double))) return rc;
+  mvk_detail_out dd{};
+  const size_t det_rows[6] = {1, 1, static_cast<size_t>(NL), 1, 3, static_cast<size_t>(2 * NL)};
+  double* host_det[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (det) {
+    host_det[0] = det->fc_t_min; host_det[1] = det->fc_rp_min; host_det[2] = det->thrust;
+    host_det[3] = det->rp_position_margin; host_det[4] = det->cog; host_det[5] = det->gimbal;
+    if (det->gimbal && !c->model.has_gimbal) return fail(MVK_ERR_INVALID_ARG, "gimbal output requested for a robot without gimbals");
+    double** dev_slot[6] = {&dd.fc_t_min, &dd.fc_rp_min, &dd.thrust, &dd.rp_position_margin, &dd.cog, &dd.gimbal};
+    for (int k = 0; k < 6; ++k)
+      if (host_det[k]) {
+        if (int rc = c->det[k].reserve(dld * det_rows[k] * sizeof(double))) return rc;
+        *dev_slot[k] = static_cast<double*>(c->det[k].p);
+      }
+  }
+  // the device detail rows use pitch dld, which run_eval_dev reads from `ld`
+  if (int rc = run_eval_dev(c, static_cast<const double*>(c->in_a.p), n, dld, layout,
+                            flags ? static_cast<uint8_t*>(c->flags.p) : nullptr, nullptr,
+                            min_dist ? static_cast<double*>(c->mind.p) : nullptr,
+                            margin ? static_cast<double*>(c->margin.p) : nullptr,
+                            band ? static_cast<uint8_t*>(c->band.p) : nullptr, det ? &dd : nullptr, force_full, s))
+    return rc;
+  if (flags) HIP_TRY(hipMemcpyAsync(flags, c->flags.p, n, hipMemcpyDeviceToHost, s));
+  if (band) HIP_TRY(hipMemcpyAsync(band, c->band.p, n, hipMemcpyDeviceToHost, s));
+  if (min_dist) HIP_TRY(hipMemcpyAsync(min_dist, c->mind.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (margin) HIP_TRY(hipMemcpyAsync(margin, c->margin.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  for (int k = 0; k < 6; ++k)
+    if (host_det[k])
+      if (int rc = copy_rows(host_det[k], ld, c->det[k].p, dld, sizeof(double), n, det_rows[k], hipMemcpyDeviceToHost, s)) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  return MVK_OK;
+}
+}  // namespace
+
+extern "C" int mvk_is_valid_batch(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, uint8_t* flags,
+                                  double* min_dist, double* margin, uint8_t* band) {
+  if (!flags && !min_dist && !margin && !band) return fail(MVK_ERR_INVALID_ARG, "no output requested");
+  return eval_host(c, soa, n, ld, layout, flags, min_dist, margin, band, nullptr, false);
+}
+
+extern "C" int mvk_eval_batch(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, uint8_t* flags,
+                              double* min_dist, double* margin, uint8_t* band, const mvk_detail_out* detail) {
+  return eval_host(c, soa, n, ld, layout, flags, min_dist, margin, band, detail, true);
+}
+
+extern "C" int mvk_is_valid(mvk_ctx* c, const double* state, mvk_result* out) {
+  if (!c || !state || !out) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  uint8_t flag = 0, band = 0;
+  double md = 0.0, mg = 0.0;
+  if (int rc = eval_host(c, state, 1, 1, MVK_LAYOUT_OMPL, &flag, &md, &mg, &band, nullptr, true)) return rc;
+  EvalArgs a;
+  base_args(c, a);
+  out->valid = flag;
+  out->band = band;
+  out->min_dist = md;
+  out->margin = mg;
+  out->stable = mg >= 0.0 ? 1 : 0;
+  out->collision = (a.do_coll && md <= 0.0) ? 1 : 0;
+  return MVK_OK;
+}
+
+extern "C" int mvk_reduce_stats(mvk_ctx* c, mvk_stats* out) {
+  if (!c || !out) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  if (!c->stats_valid) return fail(MVK_ERR_INVALID_ARG, "mvk_reduce_stats: the last call on this ctx was not a full evaluation");
+  HIP_TRY(hipSetDevice(c->device));
+  if (int rc = c->stats_out.reserve(sizeof(StatsPartial))) return rc;
+  // The evaluating kernel may have been enqueued on a caller stream: wait for the device.
+  HIP_TRY(hipDeviceSynchronize());
+  const int e = launch_stats_final(static_cast<const StatsPartial*>(c->partial.p), c->last_blocks,
+                                   static_cast<StatsPartial*>(c->stats_out.p), c->stream);
+  if (e != hipSuccess) return fail(MVK_ERR_HIP, "stats kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+  StatsPartial h;
+  HIP_TRY(hipMemcpyAsync(&h, c->stats_out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  out->n = c->last_n;
+  out->valid_count = h.valid_count;
+  out->band_count = h.band_count;
+  out->min_dist = h.min_dist; out->min_dist_index = h.min_dist_index;
+  out->min_margin = h.min_margin; out->min_margin_index = h.min_margin_index;
+  out->max_thrust = h.max_thrust; out->max_thrust_index = h.max_thrust_index;
+  out->min_thrust = h.min_thrust; out->min_thrust_index = h.min_thrust_index;
+  out->min_rp_position_margin = h.min_rp; out->min_rp_position_margin_index = h.min_rp_index;
+  return MVK_OK;
+}
+
+// ---- motion validation -----------------------------------------------------------
+namespace {
+// d_edge_off: exclusive prefix of clamp(nd,1) (device), total = number of steps
+int run_edges_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_edges, size_t ld,
+                  const int32_t* d_nd, const int64_t* d_edge_off, uint64_t total, int32_t nd_uniform,
+                  uint8_t* d_ok, int32_t* d_first, hipStream_t s) {
+  EvalArgs a;
+  base_args(c, a);
+  a.s1 = d_s1;
+  a.s2 = d_s2;
+  a.nd = d_nd;
+  a.edge_off = d_edge_off;
+  a.nd_uniform = nd_uniform < 1 ? 1 : nd_uniform;
+  a.n = total;
+  a.n_edges = n_edges;
+  a.ld = ld;
+  a.layout = MVK_LAYOUT_OMPL;
+  a.first_invalid = d_first;
+  c->stats_valid = false;
+  int e = launch_edge_init(d_first, d_nd, a.nd_uniform, n_edges, s);
+  if (e == hipSuccess) e = launch_eval(a, c->model.robot_type, c->model.n_rotor, true, s);
+  if (e == hipSuccess && d_ok) e = launch_edge_finish(d_first, d_nd, a.nd_uniform, d_ok, n_edges, s);
+  if (e != hipSuccess) return fail(MVK_ERR_HIP, "edge kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+  return MVK_OK;
+}
+
+int prefix_counts(const int32_t* nd, size_t n, std::vector<int64_t>& off, uint64_t& total) {
+  off.resize(n);
+  total = 0;
+  for (size_t e = 0; e < n; ++e) {
+    off[e] = static_cast<int64_t>(total);
+    total += static_cast<uint64_t>(nd[e] < 1 ? 1 : nd[e]);
+  }
+  return MVK_OK;
+}
+}  // namespace
+
+extern "C" int mvk_check_motion_batch_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_edges,
+                                          size_t ld, const int32_t* d_nd, int32_t nd_uniform, uint8_t* d_ok,
+                                          int32_t* d_first_invalid, void* stream) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  if (n_edges == 0) return MVK_OK;
+  if (!d_s1 || !d_s2 || ld < n_edges) return fail(MVK_ERR_INVALID_ARG, "bad edge arrays (null, or ld < n_edges)");
+  if (!d_ok && !d_first_invalid) return fail(MVK_ERR_INVALID_ARG, "no output requested");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int32_t* d_first = d_first_invalid;
+  if (!d_first) {
+    if (int rc = c->first.reserve(n_edges * sizeof(int32_t))) return rc;
+    d_first = static_cast<int32_t*>(c->first.p);
+  }
+  uint64_t total = 0;
+  const int64_t* d_off = nullptr;
+  if (d_nd) {
+    // per-edge counts: the (edge, step) -> lane map needs their prefix sums
+    std::vector<int32_t> h(n_edges);
+    HIP_TRY(hipMemcpyAsync(h.data(), d_nd, n_edges * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<int64_t> off;
+    prefix_counts(h.data(), n_edges, off, total);
+    if (int rc = c->edge_off.reserve(n_edges * sizeof(int64_t))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->edge_off.p, off.data(), n_edges * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // `off` is a local
+    d_off = static_cast<const int64_t*>(c->edge_off.p);
+  } else {
+    total = static_cast<uint64_t>(n_edges) * static_cast<uint64_t>(nd_uniform < 1 ? 1 : nd_uniform);
+  }
+  return run_edges_dev(c, d_s1, d_s2, n_edges, ld, d_nd, d_off, total, nd_uniform, d_ok, d_first, s);
+}
+
+extern "C" int mvk_check_motion_batch(mvk_ctx* c, const double* s1, const double* s2, size_t n_edges, size_t ld,
+                                      const int32_t* nd, int32_t nd_uniform, uint8_t* ok, int32_t* first_invalid) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  if (n_edges == 0) return MVK_OK;
+  if (!s1 || !s2 || ld < n_edges) return fail(MVK_ERR_INVALID_ARG, "bad edge arrays (null, or ld < n_edges)");
+  if (!ok && !first_invalid) return fail(MVK_ERR_INVALID_ARG, "no output requested");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int rows = space_dim(&c->params, c->model.n_joint);
+  const size_t dld = round_up(n_edges, 64);
+  if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
+  if (int rc = c->in_b.reserve(dld * rows * sizeof(double))) return rc;
+  if (int rc = c->first.reserve(dld * sizeof(int32_t))) return rc;
+  if (int rc = c->ok.reserve(dld)) return rc;
+  if (int rc = copy_rows(c->in_a.p, dld, s1, ld, sizeof(double), n_edges, rows, hipMemcpyHostToDevice, s)) return rc;
+  if (int rc = copy_rows(c->in_b.p, dld, s2, ld, sizeof(double), n_edges, rows, hipMemcpyHostToDevice, s)) return rc;
+  uint64_t total = 0;
+  const int32_t* d_nd = nullptr;
+  const int64_t* d_off = nullptr;
+  std::vector<int64_t> off;
+  if (nd) {
+    prefix_counts(nd, n_edges, off, total);
+    if (int rc = c->nd.reserve(n_edges * sizeof(int32_t))) return rc;
+    if (int rc = c->edge_off.reserve(n_edges * sizeof(int64_t))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->nd.p, nd, n_edges * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->edge_off.p, off.data(), n_edges * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    d_nd = static_cast<const int32_t*>(c->nd.p);
+    d_off = static_cast<const int64_t*>(c->edge_off.p);
+  } else {
+    total = static_cast<uint64_t>(n_edges) * static_cast<uint64_t>(nd_uniform < 1 ? 1 : nd_uniform);
+  }
+  if (int rc = run_edges_dev(c, static_cast<const double*>(c->in_a.p), static_cast<const double*>(c->in_b.p),
+                             n_edges, dld, d_nd, d_off, total, nd_uniform, static_cast<uint8_t*>(c->ok.p),
+                             static_cast<int32_t*>(c->first.p), s))
+    return rc;
+  if (ok) HIP_TRY(hipMemcpyAsync(ok, c->ok.p, n_edges, hipMemcpyDeviceToHost, s));
+  if (first_invalid) HIP_TRY(hipMemcpyAsync(first_invalid, c->first.p, n_edges * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return MVK_OK;
+}

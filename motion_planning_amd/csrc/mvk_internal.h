@@ -1,0 +1,101 @@
+// mvk_internal.h -- declarations shared by the translation units of libmvk.so.
+// Not part of the public ABI (that is include/mvk.h).
+#ifndef MVK_INTERNAL_H_
+#define MVK_INTERNAL_H_
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/mvk.h"
+
+namespace mvk {
+
+// record an error text for mvk_last_error() and return `code`
+int fail(int code, const char* fmt, ...);
+
+// ---- device-side views -------------------------------------------------
+// World box in the form the kernels read: centre, rotation (row-major, columns
+// are the box axes in world coordinates) and half extents.  16 doubles = 128 B.
+struct DevObs {
+  double c[3];
+  double R[9];
+  double h[3];
+  double bound;  // circumscribed-sphere radius
+};
+
+// Model constants derived once on the host.
+struct DevExtras {
+  double tan_edf_max_tilt;
+  double prim_bound[MVK_MAX_PRIM];  // radius about the primitive origin containing it
+  double prim_inner[MVK_MAX_PRIM];  // radius about the origin contained in it
+  int32_t seg_prim_begin[MVK_MAX_SEG + 1];  // primitives sorted by segment
+  int32_t prim_order[MVK_MAX_PRIM];
+};
+
+struct SpaceDev {  // what in-kernel interpolation needs
+  int32_t planning_mode, motion_type;
+};
+
+struct EvalArgs {
+  // state source: either a SoA batch ...
+  const double* soa;
+  // ... or edges (s1, s2 in MVK_LAYOUT_OMPL) densified in-kernel
+  const double* s1;
+  const double* s2;
+  const int32_t* nd;         // per-edge segment counts or nullptr
+  const int64_t* edge_off;   // exclusive prefix of nd (when nd != nullptr)
+  int32_t nd_uniform;
+  uint64_t n;   // samples (or total edge steps)
+  uint64_t n_edges;
+  uint64_t ld;
+  int32_t layout;
+  int32_t planning_mode, motion_type;
+  int32_t do_stab, do_coll;
+  int32_t full;  // 1: exact min distance / margin / band for every sample, no early exit
+  double eps_dist, eps_margin;
+  const mvk_model* model;
+  const DevExtras* extras;
+  const DevObs* obs;
+  int32_t n_obs;
+  // outputs (nullable)
+  uint8_t* flags;
+  uint64_t* mask;
+  double* min_dist;
+  double* margin;
+  uint8_t* band;
+  double* fc_t_min;
+  double* fc_rp_min;
+  double* thrust;
+  double* rp_margin;
+  double* cog;
+  double* gimbal;
+  int32_t* first_invalid;  // edge mode: atomicMin target
+  // per-block partial statistics (full mode) or nullptr
+  void* stats_partial;
+};
+
+struct StatsPartial {
+  unsigned long long valid_count, band_count;
+  double min_dist;   long long min_dist_index;
+  double min_margin; long long min_margin_index;
+  double max_thrust; long long max_thrust_index;
+  double min_thrust; long long min_thrust_index;
+  double min_rp;     long long min_rp_index;
+};
+
+constexpr int kBlock = 256;
+
+// launchers implemented in mvk_kernels.hip; return hipError_t as int
+int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream);
+int launch_edge_init(int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint64_t n_edges, void* stream);
+int launch_edge_finish(const int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint8_t* ok,
+                       uint64_t n_edges, void* stream);
+int launch_stats_final(const StatsPartial* partial, uint64_t n_partial, StatsPartial* out, void* stream);
+bool kernel_supported(int robot_type, int n_links);
+
+// host OMPL arithmetic (mvk_space.cpp)
+int space_dim(const mvk_params* p, int n_joint);
+
+}  // namespace mvk
+
+#endif

@@ -1,0 +1,1008 @@
+// mvk_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the batched validity engine.
+//
+// One lane = one state (a sample of a SoA batch, or one interpolation step of
+// an edge).  The path is fp64 VALU bound: a state costs
+// kiloflops of arithmetic against ~100 B of HBM traffic, so the design goals
+// are (1) no per-lane memory beyond the coalesced SoA row reads, (2) wave-uniform
+// data (model constants, obstacle boxes) fetched through scalar loads so it
+// lives in SGPRs and costs no VGPRs or LDS bandwidth, (3) divergence-free
+// broadphase sweeps with the rare exact narrowphase deferred to per-lane LDS
+// candidate lists and run once per primitive, where the primitive kind is
+// wave-uniform.
+//
+// What one state evaluation computes (V-spec), replacing
+//   MotionPlanning::isStateValid            sampling_based_method/src/motion_planning.cpp:76-164
+//   MultilinkState::setStatesFromRoot       aerial_motion_planning_msgs/src/multilink_state.cpp:98-137
+//   RobotModel::updateRobotModel/stabilityCheck   (third-party; call sites multilink_state.cpp:113, motion_planning.cpp:150)
+//   PlanningScene::checkCollision           (third-party; call site motion_planning.cpp:156-161)
+//   DiscreteMotionValidator::checkMotion    (third-party; bound at motion_planning.cpp:238,249)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <type_traits>
+
+#include "mvk_internal.h"
+
+namespace mvk {
+namespace {
+
+// ------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------
+#define DEV __device__ __forceinline__
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+DEV void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+constexpr double kPi = 3.14159265358979323846;
+
+// sin/cos for bounded arguments (joint angles, yaw, slerp arcs): two-constant
+// Cody-Waite reduction by pi/2 with FMAs, then the fdlibm minimax kernels on
+// |r| <= pi/4.  ~1 ulp for |x| < 1e5; avoids the Payne-Hanek slow path (and its
+// scratch usage) of the library sincos.
+DEV void sincos_cw(double x, double& s, double& c) {
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-fn, 1.57079632679489655800e+00, x);
+  r = fma(-fn, 6.12323399573676603587e-17, r);
+  const int q = static_cast<int>(fn);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(r * z, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const double a = (q & 1) ? cr : sr;
+  const double b = (q & 1) ? sr : cr;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+
+DEV double excess(double x, double h) {  // signed overshoot outside [-h, h]
+  return copysign(fmax(fabs(x) - h, 0.0), x);
+}
+DEV double excess_abs(double x, double h) { return fmax(fabs(x) - h, 0.0); }
+
+// tf::Matrix3x3::setRotation
+DEV void quat_to_mat(double x, double y, double z, double w, double R[9]) {
+  const double d = x * x + y * y + z * z + w * w;
+  const double s = 2.0 / d;
+  const double xs = x * s, ys = y * s, zs = z * s;
+  const double wx = w * xs, wy = w * ys, wz = w * zs;
+  const double xx = x * xs, xy = x * ys, xz = x * zs;
+  const double yy = y * ys, yz = y * zs, zz = z * zs;
+  R[0] = 1.0 - (yy + zz); R[1] = xy - wz;         R[2] = xz + wy;
+  R[3] = xy + wz;         R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+  R[6] = xz - wy;         R[7] = yz + wx;         R[8] = 1.0 - (xx + yy);
+}
+
+// R <- R * Rot(AXIS, angle) : mixes columns a = AXIS+1, b = AXIS+2 (mod 3)
+template <int AXIS>
+DEV void rot_cols(double R[9], double c, double s) {
+  constexpr int a = (AXIS + 1) % 3, b = (AXIS + 2) % 3;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double ua = R[3 * r + a], ub = R[3 * r + b];
+    R[3 * r + a] = fma(c, ua, s * ub);
+    R[3 * r + b] = fma(c, ub, -s * ua);
+  }
+}
+DEV void rot_cols_dyn(double R[9], int axis, double c, double s) {  // axis is wave-uniform
+  if (axis == 0) rot_cols<0>(R, c, s);
+  else if (axis == 1) rot_cols<1>(R, c, s);
+  else rot_cols<2>(R, c, s);
+}
+// y = p + R * t
+DEV void xform(const double R[9], const double p[3], double tx, double ty, double tz, double y[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) y[r] = fma(R[3 * r], tx, fma(R[3 * r + 1], ty, fma(R[3 * r + 2], tz, p[r])));
+}
+// C = A * B (row-major)
+DEV void mat_mul(const double A[9], const double B[9], double C[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      C[3 * r + c] = fma(A[3 * r], B[c], fma(A[3 * r + 1], B[3 + c], A[3 * r + 2] * B[6 + c]));
+}
+
+// ------------------------------------------------------------------------
+// narrowphase (all in the obstacle's frame; exact, closed form)
+// ------------------------------------------------------------------------
+DEV double seg_grad(const double p0[3], const double d[3], const double h[3], double t) {
+  double g = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g = fma(d[k], excess(fma(t, d[k], p0[k]), h[k]), g);
+  return g;  // half the derivative of dist^2 along the segment
+}
+
+// squared distance between the segment p0 + t d (t in [0,1]) and the solid box
+// [-h,h]^3.  dist^2(t) is convex piecewise quadratic, so its derivative is
+// nondecreasing piecewise linear with breakpoints where a coordinate crosses
+// +-h: bracket the zero between the two neighbouring breakpoints, interpolate.
+DEV double seg_box_dist2(const double p0[3], const double d[3], const double h[3]) {
+  const double g0 = seg_grad(p0, d, h, 0.0), g1 = seg_grad(p0, d, h, 1.0);
+  double tlo = 0.0, glo = g0, thi = 1.0, ghi = g1;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double inv = 1.0 / d[k];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const double t = ((sg ? -h[k] : h[k]) - p0[k]) * inv;
+      if (t > 0.0 && t < 1.0) {  // false for NaN / inf (d[k] == 0)
+        const double g = seg_grad(p0, d, h, t);
+        if (g < 0.0) {
+          if (t > tlo) { tlo = t; glo = g; }
+        } else if (t < thi) { thi = t; ghi = g; }
+      }
+    }
+  }
+  double ts = (ghi > glo) ? fma(thi - tlo, -glo / (ghi - glo), tlo) : tlo;
+  ts = (g1 <= 0.0) ? 1.0 : ts;
+  ts = (g0 >= 0.0) ? 0.0 : ts;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double e = excess_abs(fma(ts, d[k], p0[k]), h[k]);
+    s = fma(e, e, s);
+  }
+  return s;
+}
+
+// Separating-axis sweep for box A (centre t, axes = columns of R, half extents a;
+// all expressed in box B's frame) against B = [-b,b]^3.
+// METRIC: gaps of the 9 edge-edge axes are divided by the axis length so the
+// result is the largest metric gap (> 0 separated, <= 0: -penetration depth).
+// Otherwise only its sign is meaningful.
+template <bool METRIC>
+DEV double box_box_sat(const double t[3], const double R[9], const double a[3], const double b[3]) {
+  double Q[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Q[i] = fabs(R[i]);
+  double best = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {  // B's face normals (frame axes)
+    const double g = fabs(t[i]) - (b[i] + fma(a[0], Q[3 * i], fma(a[1], Q[3 * i + 1], a[2] * Q[3 * i + 2])));
+    best = fmax(best, g);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {  // A's face normals (columns of R)
+    const double proj = fma(t[0], R[j], fma(t[1], R[3 + j], t[2] * R[6 + j]));
+    const double g = fabs(proj) - (a[j] + fma(b[0], Q[j], fma(b[1], Q[3 + j], b[2] * Q[6 + j])));
+    best = fmax(best, g);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)  // axes  B_i x A_j
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const double len2 = fma(-R[3 * i + j], R[3 * i + j], 1.0);
+      const double rb = fma(b[i1], Q[3 * i2 + j], b[i2] * Q[3 * i1 + j]);
+      const double ra = fma(a[j1], Q[3 * i + j2], a[j2] * Q[3 * i + j1]);
+      double g = fabs(fma(t[i2], R[3 * i1 + j], -t[i1] * R[3 * i2 + j])) - (ra + rb);
+      if (METRIC) g = g / sqrt(len2);
+      g = (len2 < 1e-12) ? -INFINITY : g;  // parallel edges: axis degenerate, skip
+      best = fmax(best, g);
+    }
+  return best;
+}
+
+// min over the 12 edges of box A (in B's frame) of the squared distance to solid B
+DEV double box_edges_to_box2(const double c[3], const double R[9], const double a[3], const double b[3]) {
+  double best = INFINITY;
+#pragma unroll 1
+  for (int e = 0; e < 12; ++e) {  // rolled on purpose: 12 copies of seg_box_dist2 would bloat the kernel
+    const int ax = e >> 2;
+    const double su = (e & 1) ? 1.0 : -1.0, sv = (e & 2) ? 1.0 : -1.0;
+    double p0[3], d[3];
+    // columns selected by wave-uniform ax without dynamic register indexing
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double cx = R[3 * k], cy = R[3 * k + 1], cz = R[3 * k + 2];
+      const double Aax = ax == 0 ? cx : (ax == 1 ? cy : cz);
+      const double Au = ax == 0 ? cy : (ax == 1 ? cz : cx);
+      const double Av = ax == 0 ? cz : (ax == 1 ? cx : cy);
+      const double hax = ax == 0 ? a[0] : (ax == 1 ? a[1] : a[2]);
+      const double hu = ax == 0 ? a[1] : (ax == 1 ? a[2] : a[0]);
+      const double hv = ax == 0 ? a[2] : (ax == 1 ? a[0] : a[1]);
+      const double mid = fma(su * hu, Au, fma(sv * hv, Av, c[k]));
+      p0[k] = fma(-hax, Aax, mid);
+      d[k] = 2.0 * hax * Aax;
+    }
+    best = fmin(best, seg_box_dist2(p0, d, b));
+  }
+  return best;
+}
+
+// ------------------------------------------------------------------------
+// per-state evaluation
+// ------------------------------------------------------------------------
+struct StateOut {
+  bool valid, band, stable, collision;
+  double min_dist, margin, fc_t_min, fc_rp_min, rp_margin, lam_min, lam_max;
+};
+
+template <int ROBOT, int NL>
+struct Shape {
+  static constexpr bool kGimbal = ROBOT == MVK_ROBOT_DRAGON;
+  static constexpr int kSeg = kGimbal ? 2 * NL - 1 : NL;
+  static constexpr int kJoint = kGimbal ? 2 * (NL - 1) : NL - 1;
+  static constexpr int kDof = kGimbal ? 3 : 4;
+  // joint axis of segment k (compile time): HYDRUS yaw chain; DRAGON pitch (odd) / yaw (even)
+  static constexpr int axis(int k) { return kGimbal ? ((k & 1) ? 1 : 2) : 2; }
+  static constexpr int joint(int k) { return k - 1; }
+  static constexpr int rotor_seg(int i) { return kGimbal ? 2 * i : i; }
+};
+
+constexpr int kListCap = 24;  // per-lane narrowphase candidates per primitive
+
+struct Smem {
+  // [2*J][kBlock] cos/sin of the planned joints, lane-contiguous
+  double* cs;
+  // [kListCap][kBlock] candidate obstacle ids
+  unsigned short* list;
+};
+
+// gimbal (roll, pitch) that turn the thrust axis onto the CoG z axis
+// (Dragon::HydrusLikeRobotModel).  zl = CoG z axis in the link frame.
+DEV void gimbal_cs(double zlx, double zly, double zlz, double& cr, double& sr, double& cp, double& sp) {
+  const double rho = sqrt(fma(zly, zly, zlz * zlz));
+  const bool deg = !(rho > 0.0);
+  const double ir = 1.0 / rho;
+  cr = deg ? 1.0 : zlz * ir;   // roll  = atan2(-zly, zlz)
+  sr = deg ? 0.0 : -zly * ir;
+  const double w = fma(-zly, sr, zlz * cr);  // = rho
+  const double n = 1.0 / sqrt(fma(zlx, zlx, w * w));
+  cp = w * n;                  // pitch = atan2(zlx, w)
+  sp = zlx * n;
+}
+
+template <int ROBOT, int NL, bool FULL>
+DEV void eval_state(const EvalArgs& A, const double st[7 + Shape<ROBOT, NL>::kJoint], const Smem& sm,
+                    uint64_t gi, StateOut& out, double* thrust_out /*[NL] or nullptr*/) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NS = S::kSeg, NJ = S::kJoint, D = S::kDof;
+  const mvk_model* __restrict__ M = A.model;
+  const int tid = threadIdx.x;
+
+  out.valid = false; out.band = false; out.stable = false; out.collision = false;
+  out.min_dist = INFINITY; out.margin = INFINITY;
+  out.fc_t_min = NAN; out.fc_rp_min = NAN; out.rp_margin = NAN; out.lam_min = NAN; out.lam_max = NAN;
+
+  double Rw[9];
+  quat_to_mat(st[3], st[4], st[5], st[6], Rw);
+  bool finite = true;
+#pragma unroll
+  for (int k = 0; k < 7 + NJ; ++k) finite = finite && isfinite(st[k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) finite = finite && isfinite(Rw[k]);
+
+  // joint cos/sin -> LDS (read back by the rolled collision walk)
+  double jc[NJ], js[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    sincos_cw(st[7 + j], js[j], jc[j]);
+    sm.cs[(2 * j) * kBlock + tid] = jc[j];
+    sm.cs[(2 * j + 1) * kBlock + tid] = js[j];
+  }
+
+  // ---- walk 1: FK, centre of gravity, rotor geometry ----------------------
+  double R[9], p[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = Rw[k];
+  p[0] = st[0]; p[1] = st[1]; p[2] = st[2];
+  double cog[3] = {0.0, 0.0, 0.0}, mass = 0.0;
+  double P[NL][3], U[NL][3];
+  double E[S::kGimbal ? 2 * NL : 1][3];
+  static_for<0, NS>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if (k > 0) {
+      double pn[3];
+      xform(R, p, M->seg_t[k][0], M->seg_t[k][1], M->seg_t[k][2], pn);
+      p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+      rot_cols<S::axis(k)>(R, jc[S::joint(k)], js[S::joint(k)]);
+    }
+    const double mk = M->seg_mass[k];
+    double cw[3];
+    xform(R, p, M->seg_com[k][0], M->seg_com[k][1], M->seg_com[k][2], cw);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cog[c] = fma(mk, cw[c], cog[c]);
+    mass += mk;
+    const bool is_rotor_seg = S::kGimbal ? ((k & 1) == 0) : true;
+    if (is_rotor_seg) {
+      const int i = S::kGimbal ? k / 2 : k;
+      xform(R, p, M->rotor_pos[i][0], M->rotor_pos[i][1], M->rotor_pos[i][2], P[i]);
+      if (S::kGimbal) {
+        double cr, sr, cp, sp;
+        gimbal_cs(R[6], R[7], R[8], cr, sr, cp, sp);
+        if (A.gimbal) {  // getGimbalProcessedJoint (multilink_state.cpp:136)
+          A.gimbal[(2 * i) * A.ld + gi] = atan2(-R[7], R[8]);
+          A.gimbal[(2 * i + 1) * A.ld + gi] = atan2(R[6], fma(-R[7], sr, R[8] * cr));
+        }
+        // thrust axis = R * Rx(roll) * Ry(pitch) * z ;  EDFs at +-y of the pitch frame
+        const double ux = sp, uy = -sr * cp, uz = cr * cp;
+        const double ey = cr, ez = sr;  // Rx(roll) * y = (0, cr, sr)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          U[i][r] = fma(R[3 * r], ux, fma(R[3 * r + 1], uy, R[3 * r + 2] * uz));
+          const double yw = fma(R[3 * r + 1], ey, R[3 * r + 2] * ez) * M->edf_offset_y;
+          E[2 * i][r] = P[i][r] + yw;
+          E[2 * i + 1][r] = P[i][r] - yw;
+        }
+      } else {
+        U[i][0] = R[2]; U[i][1] = R[5]; U[i][2] = R[8];
+      }
+    }
+  });
+  const double inv_mass = 1.0 / mass;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) cog[c] *= inv_mass;
+  if (A.cog) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) A.cog[c * A.ld + gi] = cog[c];
+  }
+  // CoG frame is world aligned (cog_desire = q_root * R(root->baselink), baselink == root)
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) P[i][c] -= cog[c];
+
+  // ---- statics ------------------------------------------------------------
+  const double fmaxT = M->thrust_max;
+  double V[NL][3];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const double ks = M->m_f_rate * M->rotor_sigma[i];
+    V[i][0] = fma(P[i][1], U[i][2], fma(-P[i][2], U[i][1], ks * U[i][0]));
+    V[i][1] = fma(P[i][2], U[i][0], fma(-P[i][0], U[i][2], ks * U[i][1]));
+    V[i][2] = fma(P[i][0], U[i][1], fma(-P[i][1], U[i][0], ks * U[i][2]));
+  }
+  // static thrust  lambda = A^T (A A^T)^-1 b  on rows {fz, tx, ty, (tz)}
+  double G[D][D];
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const double ar = r == 0 ? U[i][2] : V[i][r - 1];
+        const double ac = c == 0 ? U[i][2] : V[i][c - 1];
+        s = fma(ar, ac, s);
+      }
+      G[r][c] = s;
+    }
+  double trace = 0.0;
+#pragma unroll
+  for (int r = 0; r < D; ++r) trace += G[r][r];
+  double Lm[D][D], Linv[D];
+  bool singular = false;
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      double s = G[r][c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) s = fma(-Lm[r][k], Lm[c][k], s);
+      if (r == c) {
+        singular = singular || !(s > 1e-14 * trace);
+        Lm[r][r] = sqrt(s);
+        Linv[r] = 1.0 / Lm[r][r];
+      } else {
+        Lm[r][c] = s * Linv[c];
+      }
+    }
+  double zf[D], yb[D];
+#pragma unroll
+  for (int r = 0; r < D; ++r) {
+    double s = r == 0 ? mass * M->gravity : 0.0;
+#pragma unroll
+    for (int k = 0; k < r; ++k) s = fma(-Lm[r][k], zf[k], s);
+    zf[r] = s * Linv[r];
+  }
+#pragma unroll
+  for (int r = D - 1; r >= 0; --r) {
+    double s = zf[r];
+#pragma unroll
+    for (int k = r + 1; k < D; ++k) s = fma(-Lm[k][r], yb[k], s);
+    yb[r] = s * Linv[r];
+  }
+  double lam_min = INFINITY, lam_max = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    double s = U[i][2] * yb[0];
+#pragma unroll
+    for (int r = 1; r < D; ++r) s = fma(V[i][r - 1], yb[r], s);
+    s = singular ? NAN : s;
+    if (thrust_out) thrust_out[i] = s;
+    lam_min = fmin(lam_min, s);
+    lam_max = fmax(lam_max, s);
+  }
+  if (singular) { lam_min = NAN; lam_max = NAN; }
+
+  // feasible-control torque distances: unordered pairs, both orientations at once
+  double fc_t = INFINITY;
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int j = i + 1; j < NL; ++j) {
+      const double nx = fma(V[i][1], V[j][2], -V[i][2] * V[j][1]);
+      const double ny = fma(V[i][2], V[j][0], -V[i][0] * V[j][2]);
+      const double nz = fma(V[i][0], V[j][1], -V[i][1] * V[j][0]);
+      const double nn = sqrt(fma(nx, nx, fma(ny, ny, nz * nz)));
+      const double sc = (nn < 1e-5) ? 0.0 : fmaxT / nn;
+      double dp = 0.0, dm = 0.0;
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        if (k == i || k == j) continue;
+        const double tp = fma(nx, V[k][0], fma(ny, V[k][1], nz * V[k][2])) * sc;
+        dp += fmax(tp, 0.0);
+        dm += fmax(-tp, 0.0);
+      }
+      fc_t = fmin(fc_t, fmin(dp, dm));
+    }
+  // roll/pitch version
+  double fc_rp = INFINITY;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const double na = sqrt(fma(V[i][0], V[i][0], V[i][1] * V[i][1]));
+    const double sc = (na < 1e-5) ? 0.0 : fmaxT / na;
+    double d = 0.0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      if (j == i) continue;
+      d += fmax(fma(V[i][1], V[j][0], -V[i][0] * V[j][1]) * sc, 0.0);
+    }
+    fc_rp = fmin(fc_rp, d);
+  }
+  out.fc_t_min = fc_t;
+  out.fc_rp_min = fc_rp;
+  out.lam_min = lam_min;
+  out.lam_max = lam_max;
+
+  if (FULL) {  // legacy roll/pitch position margin ("minimum_var")
+    double ax = 0.0, ay = 0.0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { ax += P[i][0]; ay += P[i][1]; }
+    ax *= 1.0 / NL; ay *= 1.0 / NL;
+    double sxx = 0.0, sxy = 0.0, syy = 0.0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const double dx = P[i][0] - ax, dy = P[i][1] - ay;
+      sxx = fma(dx, dx, sxx); sxy = fma(dx, dy, sxy); syy = fma(dy, dy, syy);
+    }
+    sxx *= 1.0 / NL; sxy *= 1.0 / NL; syy *= 1.0 / NL;
+    const double hd = 0.5 * (sxx - syy);
+    const double lmin = 0.5 * (sxx + syy) - sqrt(fma(hd, hd, sxy * sxy));
+    out.rp_margin = sqrt(fmax(lmin, 0.0)) / M->link_length;
+  }
+
+  // stabilityCheck(): min slack over the active tests
+  double margin = INFINITY;
+  if (M->fc_rp_min_thre > 0.0) margin = fmin(margin, fc_rp - M->fc_rp_min_thre);
+  if (M->fc_t_min_thre > 0.0) margin = fmin(margin, fc_t - M->fc_t_min_thre);
+  margin = fmin(margin, fmin(lam_min - M->thrust_min, M->thrust_max - lam_max));
+  if (S::kGimbal) {
+    const double tt = A.extras->tan_edf_max_tilt, r2 = 2.0 * M->edf_radius;
+#pragma unroll
+    for (int a = 0; a < 2 * NL; ++a)
+#pragma unroll
+      for (int b = a + 1; b < 2 * NL; ++b) {
+        if (a / 2 == b / 2) continue;
+        const double dx = E[a][0] - E[b][0], dy = E[a][1] - E[b][1], dz = E[a][2] - E[b][2];
+        margin = fmin(margin, sqrt(fma(dx, dx, dy * dy)) - fma(fabs(dz), tt, r2));
+      }
+  }
+  if (singular) margin = -INFINITY;
+  out.margin = margin;
+  out.stable = margin >= 0.0;
+
+  // ---- walk 2: collision primitives vs world boxes --------------------------
+  // lanes that cannot change their verdict any more stop generating work
+  bool live = finite && A.do_coll && (FULL || !A.do_stab || out.stable);
+  double mind = INFINITY;  // running exact minimum (FULL) / <= 0 once a hit is found
+  if (A.do_coll && A.n_obs > 0 && __any(live)) {
+    const DevExtras* __restrict__ X = A.extras;
+    const DevObs* __restrict__ obs = A.obs;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = Rw[k];
+    p[0] = st[0]; p[1] = st[1]; p[2] = st[2];
+#pragma unroll 1
+    for (int k = 0; k < NS; ++k) {
+      if (k > 0) {
+        double pn[3];
+        xform(R, p, M->seg_t[k][0], M->seg_t[k][1], M->seg_t[k][2], pn);
+        p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+        const int jn = M->seg_joint[k];
+        const double c = sm.cs[(2 * jn) * kBlock + tid], s = sm.cs[(2 * jn + 1) * kBlock + tid];
+        rot_cols_dyn(R, M->seg_axis[k], c, s);
+      }
+#pragma unroll 1
+      for (int qi = X->seg_prim_begin[k]; qi < X->seg_prim_begin[k + 1]; ++qi) {
+        const int q = X->prim_order[qi];
+        const int type = M->prim_type[q];
+        // pose of the primitive: base frame * collision origin
+        double B[9], bp[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) B[e] = R[e];
+        bp[0] = p[0]; bp[1] = p[1]; bp[2] = p[2];
+        if (S::kGimbal && M->prim_frame[q] != MVK_FRAME_SEG) {
+          const int i = M->prim_rotor[q];
+          double o[3];
+          xform(R, p, M->rotor_pos[i][0], M->rotor_pos[i][1], M->rotor_pos[i][2], o);
+          bp[0] = o[0]; bp[1] = o[1]; bp[2] = o[2];
+          double cr, sr, cp, sp;
+          gimbal_cs(R[6], R[7], R[8], cr, sr, cp, sp);
+          rot_cols<0>(B, cr, sr);
+          if (M->prim_frame[q] == MVK_FRAME_GIMBAL_PITCH) rot_cols<1>(B, cp, sp);
+        }
+        double pc[3], PR[9];
+        xform(B, bp, M->prim_pos[q][0], M->prim_pos[q][1], M->prim_pos[q][2], pc);
+        {
+          double Lr[9];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) Lr[e] = M->prim_rot[q][e];
+          mat_mul(B, Lr, PR);
+        }
+        const double rb = X->prim_bound[q], rin = X->prim_inner[q];
+        const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+
+        // -- broadphase sweep: centre-to-box distance vs bounding radius -------
+        // obstacle boxes are read at wave-uniform addresses (scalar loads -> SGPRs)
+        auto centre_dist2 = [&](const DevObs& O) {
+          const double dx = pc[0] - O.c[0], dy = pc[1] - O.c[1], dz = pc[2] - O.c[2];
+          const double e0 = excess_abs(fma(O.R[0], dx, fma(O.R[3], dy, O.R[6] * dz)), O.h[0]);
+          const double e1 = excess_abs(fma(O.R[1], dx, fma(O.R[4], dy, O.R[7] * dz)), O.h[1]);
+          const double e2 = excess_abs(fma(O.R[2], dx, fma(O.R[5], dy, O.R[8] * dz)), O.h[2]);
+          return fma(e0, e0, fma(e1, e1, e2 * e2));
+        };
+        int cnt = 0;
+        if (FULL) {
+          // pass 1: the primitive's origin lies inside it, so min_ob dist(origin, box)
+          // bounds this primitive's separation from above
+          double best2 = INFINITY;
+#pragma unroll 2
+          for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
+          if (type == MVK_PRIM_SPHERE) {
+            mind = fmin(mind, sqrt(best2) - d0);  // exact for a sphere
+          } else {
+            // pass 2: keep pairs whose lower bound (centre distance - bounding radius)
+            // can still undercut the running minimum, and every possibly-touching pair
+            const double thr = rb + fmax(fmin(mind, sqrt(best2)), 0.0);
+            const double thr2 = thr * thr;
+#pragma unroll 2
+            for (int ob = 0; ob < A.n_obs; ++ob) {
+              if (live && centre_dist2(obs[ob]) <= thr2) {
+                if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
+                ++cnt;
+              }
+            }
+          }
+        } else {
+          const double rb2 = rb * rb, rin2 = rin * rin;
+          bool hit = false;
+#pragma unroll 2
+          for (int ob = 0; ob < A.n_obs; ++ob) {
+            const double l2 = centre_dist2(obs[ob]);
+            hit = hit || (l2 <= rin2);  // a ball inside the primitive already touches the box
+            if (type != MVK_PRIM_SPHERE && live && l2 <= rb2 && l2 > rin2) {
+              if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
+              ++cnt;
+            }
+          }
+          if (hit && live) mind = fmin(mind, 0.0);
+        }
+
+        // -- narrowphase drain: kind is wave-uniform, list length is per lane ---
+        const bool overflow = cnt > kListCap;
+        int todo = (live && (FULL || !(mind <= 0.0))) ? (overflow ? A.n_obs : cnt) : 0;
+        if (type == MVK_PRIM_SPHERE) todo = 0;
+#pragma unroll 1
+        for (int e = 0; __any(e < todo); ++e) {
+          if (e < todo) {
+            // on overflow fall back to testing every obstacle for this primitive
+            const int ob = overflow ? e : sm.list[e * kBlock + tid];
+            const DevObs O = obs[ob];
+            double t[3];
+            {
+              const double dx = pc[0] - O.c[0], dy = pc[1] - O.c[1], dz = pc[2] - O.c[2];
+              t[0] = fma(O.R[0], dx, fma(O.R[3], dy, O.R[6] * dz));
+              t[1] = fma(O.R[1], dx, fma(O.R[4], dy, O.R[7] * dz));
+              t[2] = fma(O.R[2], dx, fma(O.R[5], dy, O.R[8] * dz));
+            }
+            double d;
+            if (type == MVK_PRIM_CAPSULE) {
+              // axis = local z in world = third column of PR, into the box frame
+              double a[3];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) a[c] = fma(O.R[c], PR[2], fma(O.R[3 + c], PR[5], O.R[6 + c] * PR[8]));
+              double p0[3], dd[3];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { p0[c] = fma(-d1, a[c], t[c]); dd[c] = 2.0 * d1 * a[c]; }
+              const double s2 = seg_box_dist2(p0, dd, O.h);
+              if (FULL) d = sqrt(s2) - d0;
+              else d = (s2 <= d0 * d0) ? 0.0 : 1.0;
+            } else {
+              // box: primitive axes in the obstacle frame  Rr = O.R^T * PR
+              double Rr[9];
+#pragma unroll
+              for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                  Rr[3 * r + c] = fma(O.R[r], PR[c], fma(O.R[3 + r], PR[3 + c], O.R[6 + r] * PR[6 + c]));
+              const double a[3] = {d0, d1, d2};
+              if (FULL) {
+                d = box_box_sat<true>(t, Rr, a, O.h);
+                if (d > 0.0) {
+                  // exact separation: closest features always include a point on an edge
+                  double s2 = box_edges_to_box2(t, Rr, a, O.h);
+                  // obstacle in the primitive's frame
+                  double Rt[9], tb[3];
+#pragma unroll
+                  for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Rt[3 * r + c] = Rr[3 * c + r];
+#pragma unroll
+                  for (int r = 0; r < 3; ++r) tb[r] = -fma(Rr[r], t[0], fma(Rr[3 + r], t[1], Rr[6 + r] * t[2]));
+                  s2 = fmin(s2, box_edges_to_box2(tb, Rt, O.h, a));
+                  d = sqrt(s2);
+                }
+              } else {
+                d = box_box_sat<false>(t, Rr, a, O.h);
+              }
+            }
+            mind = fmin(mind, d);
+            if (!FULL && d <= 0.0) todo = 0;  // verdict reached
+          }
+        }
+        if (!FULL) {
+          live = live && !(mind <= 0.0);
+          if (!__any(live)) break;
+        }
+      }
+      if (!FULL && !__any(live)) break;
+    }
+  }
+  out.min_dist = (A.do_coll && finite) ? mind : INFINITY;
+  out.collision = A.do_coll && (mind <= 0.0);
+  out.valid = finite && (!A.do_stab || out.stable) && !out.collision;
+  out.band = !finite || (A.do_stab && fabs(margin) <= A.eps_margin) ||
+             (FULL && A.do_coll && fabs(mind) <= A.eps_dist);
+  if (!finite) { out.margin = -INFINITY; out.min_dist = NAN; out.stable = false; out.collision = false; }
+}
+
+// ------------------------------------------------------------------------
+// state fetch: SoA batch rows, or in-kernel edge densification
+// ------------------------------------------------------------------------
+DEV double so2_interp(double from, double to, double t) {
+  double diff = to - from;
+  if (fabs(diff) <= kPi) return fma(diff, t, from);
+  diff = (diff > 0.0) ? 2.0 * kPi - diff : -2.0 * kPi - diff;
+  double v = fma(-diff, t, from);
+  if (v > kPi) v -= 2.0 * kPi;
+  else if (v < -kPi) v += 2.0 * kPi;
+  return v;
+}
+DEV void so3_interp(const double* a, const double* b, double t, double* o) {
+  const double dq = fma(a[0], b[0], fma(a[1], b[1], fma(a[2], b[2], a[3] * b[3])));
+  const double adq = fabs(dq);
+  const double theta = (adq > 1.0 - 1e-9) ? 0.0 : acos(adq);
+  if (theta > 2.220446049250313e-16) {
+    double s0, s1, st, dummy;
+    sincos_cw(theta, st, dummy);
+    sincos_cw((1.0 - t) * theta, s0, dummy);
+    sincos_cw(t * theta, s1, dummy);
+    const double d = 1.0 / st;
+    if (dq < 0.0) s1 = -s1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fma(a[k], s0, b[k] * s1) * d;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = a[k];
+  }
+}
+
+// unpack of motion_planning.cpp:81-129 from an OMPL-layout state held in `s`
+template <int NJ>
+DEV void unpack_ompl(const EvalArgs& A, const double* s, double* st) {
+  st[0] = st[1] = st[2] = 0.0; st[3] = st[4] = st[5] = 0.0; st[6] = 1.0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) st[7 + j] = 0.0;
+  if (A.planning_mode != MVK_MODE_ONLY_JOINTS) {
+    if (A.motion_type == MVK_SE2) {
+      st[0] = s[0]; st[1] = s[1];
+      sincos_cw(0.5 * s[2], st[5], st[6]);  // createQuaternionMsgFromYaw
+    } else {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) st[k] = s[k];
+    }
+  }
+}
+
+template <int ROBOT, int NL, bool FULL, bool EDGE>
+__global__ void __launch_bounds__(kBlock) validity_kernel(const EvalArgs A) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ double sm_cs[2 * NJ * kBlock];
+  __shared__ unsigned short sm_list[kListCap * kBlock];
+  Smem sm{sm_cs, sm_list};
+
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);  // clamp: out-of-range lanes redo the last state
+
+  double st[7 + NJ];
+  uint64_t edge = 0;
+  int step = 0, nd_e = 1;
+  if (!EDGE) {
+    const double* __restrict__ src = A.soa;
+    if (A.layout == MVK_LAYOUT_POSE7) {
+#pragma unroll
+      for (int r = 0; r < 7 + NJ; ++r) st[r] = src[r * A.ld + li];
+      if (A.planning_mode == MVK_MODE_ONLY_JOINTS) {
+        st[0] = st[1] = st[2] = st[3] = st[4] = st[5] = 0.0; st[6] = 1.0;
+      }
+      if (A.planning_mode == MVK_MODE_ONLY_BASE) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) st[7 + j] = 0.0;
+      }
+    } else {
+      double s[7];
+      const int nb = (A.planning_mode == MVK_MODE_ONLY_JOINTS) ? 0 : (A.motion_type == MVK_SE2 ? 3 : 7);
+#pragma unroll
+      for (int r = 0; r < 7; ++r) s[r] = (r < nb) ? src[r * A.ld + li] : 0.0;
+      unpack_ompl<NJ>(A, s, st);
+      if (A.planning_mode != MVK_MODE_ONLY_BASE) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) st[7 + j] = src[(nb + j) * A.ld + li];
+      }
+    }
+  } else {
+    // lane -> (edge, step): step j in 1..nd tests interp(s1, s2, j/nd); j = nd is s2 itself
+    if (A.nd == nullptr) {
+      nd_e = A.nd_uniform;
+      edge = li / static_cast<uint64_t>(nd_e);
+      step = static_cast<int>(li - edge * nd_e) + 1;
+    } else {
+      uint64_t lo = 0, hi = A.n_edges;  // largest e with edge_off[e] <= li
+      while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (static_cast<uint64_t>(A.edge_off[mid]) <= li) lo = mid; else hi = mid;
+      }
+      edge = lo;
+      nd_e = A.nd[edge] < 1 ? 1 : A.nd[edge];
+      step = static_cast<int>(li - static_cast<uint64_t>(A.edge_off[edge])) + 1;
+    }
+    const double t = static_cast<double>(step) / static_cast<double>(nd_e);
+    const bool last = step == nd_e;
+    const int nb = (A.planning_mode == MVK_MODE_ONLY_JOINTS) ? 0 : (A.motion_type == MVK_SE2 ? 3 : 7);
+    double a[7], b[7], s[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      a[r] = (r < nb) ? A.s1[r * A.ld + edge] : 0.0;
+      b[r] = (r < nb) ? A.s2[r * A.ld + edge] : 0.0;
+      s[r] = b[r];
+    }
+    if (!last && nb > 0) {
+      if (A.motion_type == MVK_SE2) {
+        s[0] = fma(b[0] - a[0], t, a[0]);
+        s[1] = fma(b[1] - a[1], t, a[1]);
+        s[2] = so2_interp(a[2], b[2], t);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] = fma(b[k] - a[k], t, a[k]);
+        so3_interp(a + 3, b + 3, t, s + 3);
+      }
+    }
+    unpack_ompl<NJ>(A, s, st);
+    if (A.planning_mode != MVK_MODE_ONLY_BASE) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const double ja = A.s1[(nb + j) * A.ld + edge], jb = A.s2[(nb + j) * A.ld + edge];
+        st[7 + j] = last ? jb : fma(jb - ja, t, ja);
+      }
+    }
+  }
+
+  StateOut o;
+  double thrust[NL];
+  eval_state<ROBOT, NL, FULL>(A, st, sm, li, o, FULL ? thrust : nullptr);
+
+  if (!EDGE) {
+    if (in_range) {
+      if (A.flags) A.flags[gi] = o.valid ? 1 : 0;
+      if (A.band) A.band[gi] = o.band ? 1 : 0;
+      if (FULL) {
+        if (A.min_dist) A.min_dist[gi] = o.min_dist;
+        if (A.margin) A.margin[gi] = o.margin;
+        if (A.fc_t_min) A.fc_t_min[gi] = o.fc_t_min;
+        if (A.fc_rp_min) A.fc_rp_min[gi] = o.fc_rp_min;
+        if (A.rp_margin) A.rp_margin[gi] = o.rp_margin;
+        if (A.thrust) {
+#pragma unroll
+          for (int i = 0; i < NL; ++i) A.thrust[i * A.ld + gi] = thrust[i];
+        }
+      }
+    }
+    if (A.mask) {
+      const unsigned long long bal = __ballot(in_range && o.valid);
+      if ((threadIdx.x & 63) == 0 && (gi - (gi & 63)) < A.n) A.mask[gi >> 6] = bal;
+    }
+  } else {
+    if (in_range && !o.valid) atomicMin(&A.first_invalid[edge], step);
+    if (A.band && in_range && o.band) A.band[edge] = 1;
+  }
+
+  // ---- per-block statistics (FULL batches): motion_planning.cpp:615-632 extrema ---
+  if (FULL && !EDGE && A.stats_partial) {
+    __shared__ StatsPartial sm_part[kBlock / 64];
+    StatsPartial mine;
+    const long long idx = static_cast<long long>(gi);
+    mine.valid_count = (in_range && o.valid) ? 1 : 0;
+    mine.band_count = (in_range && o.band) ? 1 : 0;
+    const bool use = in_range;
+    mine.min_dist = (use && !isnan(o.min_dist)) ? o.min_dist : INFINITY;  mine.min_dist_index = idx;
+    mine.min_margin = (use && !isnan(o.margin)) ? o.margin : INFINITY;    mine.min_margin_index = idx;
+    mine.max_thrust = (use && !isnan(o.lam_max)) ? o.lam_max : -INFINITY; mine.max_thrust_index = idx;
+    mine.min_thrust = (use && !isnan(o.lam_min)) ? o.lam_min : INFINITY;  mine.min_thrust_index = idx;
+    mine.min_rp = (use && !isnan(o.rp_margin)) ? o.rp_margin : INFINITY;  mine.min_rp_index = idx;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mine.valid_count += __shfl_xor(mine.valid_count, off);
+      mine.band_count += __shfl_xor(mine.band_count, off);
+      auto red_min = [&](double& v, long long& ix) {
+        const double ov = __shfl_xor(v, off);
+        const long long oi = __shfl_xor(ix, off);
+        if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+      };
+      auto red_max = [&](double& v, long long& ix) {
+        const double ov = __shfl_xor(v, off);
+        const long long oi = __shfl_xor(ix, off);
+        if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+      };
+      red_min(mine.min_dist, mine.min_dist_index);
+      red_min(mine.min_margin, mine.min_margin_index);
+      red_max(mine.max_thrust, mine.max_thrust_index);
+      red_min(mine.min_thrust, mine.min_thrust_index);
+      red_min(mine.min_rp, mine.min_rp_index);
+    }
+    if ((threadIdx.x & 63) == 0) sm_part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      StatsPartial acc = sm_part[0];
+      for (int w = 1; w < kBlock / 64; ++w) {
+        const StatsPartial& q = sm_part[w];
+        acc.valid_count += q.valid_count;
+        acc.band_count += q.band_count;
+        if (q.min_dist < acc.min_dist || (q.min_dist == acc.min_dist && q.min_dist_index < acc.min_dist_index)) { acc.min_dist = q.min_dist; acc.min_dist_index = q.min_dist_index; }
+        if (q.min_margin < acc.min_margin || (q.min_margin == acc.min_margin && q.min_margin_index < acc.min_margin_index)) { acc.min_margin = q.min_margin; acc.min_margin_index = q.min_margin_index; }
+        if (q.max_thrust > acc.max_thrust || (q.max_thrust == acc.max_thrust && q.max_thrust_index < acc.max_thrust_index)) { acc.max_thrust = q.max_thrust; acc.max_thrust_index = q.max_thrust_index; }
+        if (q.min_thrust < acc.min_thrust || (q.min_thrust == acc.min_thrust && q.min_thrust_index < acc.min_thrust_index)) { acc.min_thrust = q.min_thrust; acc.min_thrust_index = q.min_thrust_index; }
+        if (q.min_rp < acc.min_rp || (q.min_rp == acc.min_rp && q.min_rp_index < acc.min_rp_index)) { acc.min_rp = q.min_rp; acc.min_rp_index = q.min_rp_index; }
+      }
+      static_cast<StatsPartial*>(A.stats_partial)[blockIdx.x] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
+// small helper kernels
+// ------------------------------------------------------------------------
+__global__ void edge_init_kernel(int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint64_t n) {
+  const uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e < n) {
+    const int v = nd ? nd[e] : nd_uniform;
+    first_invalid[e] = (v < 1 ? 1 : v) + 1;
+  }
+}
+__global__ void edge_finish_kernel(const int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform,
+                                   uint8_t* ok, uint64_t n) {
+  const uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e < n) {
+    const int v = nd ? nd[e] : nd_uniform;
+    ok[e] = first_invalid[e] == (v < 1 ? 1 : v) + 1 ? 1 : 0;
+  }
+}
+__global__ void stats_final_kernel(const StatsPartial* part, uint64_t n, StatsPartial* out) {
+  // one block of 256 threads strides over the partials, then a serial merge in LDS
+  __shared__ StatsPartial sm[256];
+  StatsPartial acc;
+  acc.valid_count = 0; acc.band_count = 0;
+  acc.min_dist = INFINITY; acc.min_dist_index = -1;
+  acc.min_margin = INFINITY; acc.min_margin_index = -1;
+  acc.max_thrust = -INFINITY; acc.max_thrust_index = -1;
+  acc.min_thrust = INFINITY; acc.min_thrust_index = -1;
+  acc.min_rp = INFINITY; acc.min_rp_index = -1;
+  auto merge = [](StatsPartial& a, const StatsPartial& q) {
+    a.valid_count += q.valid_count;
+    a.band_count += q.band_count;
+    auto lt = [](double v, long long i, double w, long long j) { return v < w || (v == w && (j < 0 || (i >= 0 && i < j))); };
+    if (lt(q.min_dist, q.min_dist_index, a.min_dist, a.min_dist_index)) { a.min_dist = q.min_dist; a.min_dist_index = q.min_dist_index; }
+    if (lt(q.min_margin, q.min_margin_index, a.min_margin, a.min_margin_index)) { a.min_margin = q.min_margin; a.min_margin_index = q.min_margin_index; }
+    if (lt(-q.max_thrust, q.max_thrust_index, -a.max_thrust, a.max_thrust_index)) { a.max_thrust = q.max_thrust; a.max_thrust_index = q.max_thrust_index; }
+    if (lt(q.min_thrust, q.min_thrust_index, a.min_thrust, a.min_thrust_index)) { a.min_thrust = q.min_thrust; a.min_thrust_index = q.min_thrust_index; }
+    if (lt(q.min_rp, q.min_rp_index, a.min_rp, a.min_rp_index)) { a.min_rp = q.min_rp; a.min_rp_index = q.min_rp_index; }
+  };
+  for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) merge(acc, part[i]);
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    StatsPartial tot = sm[0];
+    for (int t = 1; t < 256; ++t) merge(tot, sm[t]);
+    *out = tot;
+  }
+}
+
+template <int ROBOT, int NL>
+int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s) {
+  const uint64_t blocks = (a.n + kBlock - 1) / kBlock;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+  dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+  if (edge_mode) {
+    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, true>), g, b, 0, s, a);
+  } else if (a.full) {
+    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, true, false>), g, b, 0, s, a);
+  } else {
+    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, false>), g, b, 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool kernel_supported(int robot_type, int n_links) {
+  if (robot_type == MVK_ROBOT_HYDRUS) return n_links == 4 || n_links == 6 || n_links == 8;
+  if (robot_type == MVK_ROBOT_DRAGON) return n_links == 4;
+  return false;
+}
+
+int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (robot_type == MVK_ROBOT_HYDRUS) {
+    switch (n_links) {
+      case 4: return launch_shape<MVK_ROBOT_HYDRUS, 4>(a, edge_mode, s);
+      case 6: return launch_shape<MVK_ROBOT_HYDRUS, 6>(a, edge_mode, s);
+      case 8: return launch_shape<MVK_ROBOT_HYDRUS, 8>(a, edge_mode, s);
+      default: break;
+    }
+  } else if (robot_type == MVK_ROBOT_DRAGON) {
+    if (n_links == 4) return launch_shape<MVK_ROBOT_DRAGON, 4>(a, edge_mode, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+int launch_edge_init(int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint64_t n_edges, void* stream) {
+  if (n_edges == 0) return hipSuccess;
+  hipLaunchKernelGGL(edge_init_kernel, dim3(static_cast<unsigned>((n_edges + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), first_invalid, nd, nd_uniform, n_edges);
+  return hipGetLastError();
+}
+int launch_edge_finish(const int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint8_t* ok,
+                       uint64_t n_edges, void* stream) {
+  if (n_edges == 0) return hipSuccess;
+  hipLaunchKernelGGL(edge_finish_kernel, dim3(static_cast<unsigned>((n_edges + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), first_invalid, nd, nd_uniform, ok, n_edges);
+  return hipGetLastError();
+}
+int launch_stats_final(const StatsPartial* partial, uint64_t n_partial, StatsPartial* out, void* stream) {
+  hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partial,
+                     n_partial, out);
+  return hipGetLastError();
+}
+
+}  // namespace mvk
