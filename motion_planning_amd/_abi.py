@@ -127,6 +127,13 @@ def load():
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no Python / CPU fallback for the validity kernels)")
+    # A process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64; when tensors are going
+    # to be shared with this library (tests, bench.py) torch has to be loaded first so that libmvk.so binds to
+    # the runtime torch already brought in (loading /opt/rocm's copy first leaves torch without devices).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

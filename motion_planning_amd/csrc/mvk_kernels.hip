@@ -272,11 +272,11 @@ DEV void gimbal_cs(double zlx, double zly, double zlz, double& cr, double& sr, d
 }
 
 template <int ROBOT, int NL, bool FULL>
-DEV void eval_state(const EvalArgs& A, const double st[7 + Shape<ROBOT, NL>::kJoint], const Smem& sm,
-                    uint64_t gi, StateOut& out, double* thrust_out /*[NL] or nullptr*/) {
+DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                    const DevObs* __restrict__ obs, const double st[7 + Shape<ROBOT, NL>::kJoint],
+                    const Smem& sm, uint64_t gi, StateOut& out, double* thrust_out /*[NL] or nullptr*/) {
   using S = Shape<ROBOT, NL>;
   constexpr int NS = S::kSeg, NJ = S::kJoint, D = S::kDof;
-  const mvk_model* __restrict__ M = A.model;
   const int tid = threadIdx.x;
 
   out.valid = false; out.band = false; out.stable = false; out.collision = false;
@@ -497,7 +497,7 @@ DEV void eval_state(const EvalArgs& A, const double st[7 + Shape<ROBOT, NL>::kJo
   if (M->fc_t_min_thre > 0.0) margin = fmin(margin, fc_t - M->fc_t_min_thre);
   margin = fmin(margin, fmin(lam_min - M->thrust_min, M->thrust_max - lam_max));
   if (S::kGimbal) {
-    const double tt = A.extras->tan_edf_max_tilt, r2 = 2.0 * M->edf_radius;
+    const double tt = X->tan_edf_max_tilt, r2 = 2.0 * M->edf_radius;
 #pragma unroll
     for (int a = 0; a < 2 * NL; ++a)
 #pragma unroll
@@ -516,8 +516,6 @@ DEV void eval_state(const EvalArgs& A, const double st[7 + Shape<ROBOT, NL>::kJo
   bool live = finite && A.do_coll && (FULL || !A.do_stab || out.stable);
   double mind = INFINITY;  // running exact minimum (FULL) / <= 0 once a hit is found
   if (A.do_coll && A.n_obs > 0 && __any(live)) {
-    const DevExtras* __restrict__ X = A.extras;
-    const DevObs* __restrict__ obs = A.obs;
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = Rw[k];
     p[0] = st[0]; p[1] = st[1]; p[2] = st[2];
@@ -734,7 +732,9 @@ DEV void unpack_ompl(const EvalArgs& A, const double* s, double* st) {
 }
 
 template <int ROBOT, int NL, bool FULL, bool EDGE>
-__global__ void __launch_bounds__(kBlock) validity_kernel(const EvalArgs A) {
+__global__ void __launch_bounds__(kBlock)
+validity_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                const DevObs* __restrict__ obs) {
   using S = Shape<ROBOT, NL>;
   constexpr int NJ = S::kJoint;
   __shared__ double sm_cs[2 * NJ * kBlock];
@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(kBlock) validity_kernel(const EvalArgs A) {
 
   StateOut o;
   double thrust[NL];
-  eval_state<ROBOT, NL, FULL>(A, st, sm, li, o, FULL ? thrust : nullptr);
+  eval_state<ROBOT, NL, FULL>(A, M, X, obs, st, sm, li, o, FULL ? thrust : nullptr);
 
   if (!EDGE) {
     if (in_range) {
@@ -954,11 +954,11 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s) {
   if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
   if (edge_mode) {
-    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, true>), g, b, 0, s, a);
+    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, true>), g, b, 0, s, a, a.model, a.extras, a.obs);
   } else if (a.full) {
-    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, true, false>), g, b, 0, s, a);
+    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, true, false>), g, b, 0, s, a, a.model, a.extras, a.obs);
   } else {
-    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, false>), g, b, 0, s, a);
+    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, false>), g, b, 0, s, a, a.model, a.extras, a.obs);
   }
   return hipGetLastError();
 }

@@ -1,0 +1,83 @@
+"""The C-ABI library loads and exports every symbol include/mvk.h declares (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import motion_planning_amd as mp
+from motion_planning_amd import _abi as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mvk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mvk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = A.load()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"libmvk.so does not export {n}"
+        assert n in A.PROTOTYPES, f"{n} has no ctypes prototype"
+    assert sorted(A.PROTOTYPES) == names
+
+
+def test_struct_layouts_match():
+    lib = A.load()
+    assert lib.mvk_model_sizeof() == C.sizeof(A.Model)
+    assert lib.mvk_params_sizeof() == C.sizeof(A.Params)
+    assert lib.mvk_abi_version() == 1
+
+
+def test_model_factories_and_argument_errors():
+    lib = A.load()
+    m = A.Model()
+    assert lib.mvk_model_hydrus(2, C.byref(m)) == A.ERR_INVALID_ARG
+    assert b"n_links" in lib.mvk_last_error()
+    for n in (4, 6, 8):
+        m = mp.make_model("hydrus", n)
+        assert (m.n_seg, m.n_joint, m.n_rotor, m.n_prim, m.wrench_dof) == (n, n - 1, n, 2 * n, 4)
+        assert abs(m.link_length - 0.6) < 1e-15          # hydrus.yaml:31
+        assert abs(m.prim_dim[1][0] - 0.2) < 1e-15       # protector radius, hydrus.yaml:32
+    d = mp.make_model("dragon", 4)
+    assert (d.n_seg, d.n_joint, d.n_rotor, d.n_prim, d.wrench_dof, d.has_gimbal) == (7, 6, 4, 15, 3, 1)
+    assert abs(d.edf_max_tilt - 0.1) < 1e-15             # dragon_quad.yaml:56
+    p = mp.default_params(d, A.MODE_JOINTS_AND_BASE, A.SE3)
+    assert (p.validity_resolution, p.valid_segment_count_factor, p.joint_subspace_weight) == (0.03, 20, 0.001)
+    assert list(p.pos_low) == [-2.0, -2.2, -2.2] and list(p.pos_high) == [5.0, 2.2, 2.2]
+
+
+@pytest.mark.skipif(A.load().mvk_device_count() > 0, reason="box has a GPU")
+def test_no_device_means_loud_failure_not_fallback():
+    lib = A.load()
+    m = mp.make_model("hydrus", 4)
+    p = mp.default_params(m, 2, 0)
+    with pytest.raises(mp.MvkError) as e:
+        mp.Engine(m, np.zeros((0, 10)), p)
+    assert "no HIP device" in str(e.value) or "not gfx950" in str(e.value)
+
+
+def test_gap_worlds_literal_numbers():
+    """squeeze_navigation/src/planner/sampling_based_method.cpp:84-112 and :116-197"""
+    h = mp.horizontal_gap_scene()
+    want = np.array([[0.15, 1.55, 0, 0, 0, 0, 1, 0.3, 2.5, 10], [0.15, -1.55, 0, 0, 0, 0, 1, 0.3, 2.5, 10],
+                     [1.0, 2.5, 0, 0, 0, 0, 1, 8, 0.6, 10], [1.0, -2.5, 0, 0, 0, 0, 1, 8, 0.6, 10]])
+    assert np.array_equal(h, want)
+    # quirk Q2: right wall keeps the LEFT wall's x size but is positioned with gap_right_width
+    h2 = mp.horizontal_gap_scene(0.1, 0.4, 0.3, 0.5)
+    assert h2[1, 0] == 0.1 + 0.25 and h2[1, 7] == 0.3
+    v = mp.vertical_gap_scene(0.5, 0.5, 0.7, True, 0.6, 2.0)   # gap.yaml:2-4
+    assert v.shape == (10, 10)
+    assert np.allclose(v[0], [5.25, 0, 0.7, 0, 0, 0, 1, 10, 10, 0.05])
+    assert np.allclose(v[3], [0, -5.25, 0.7, 0, 0, 0, 1, 10, 10, 0.05])
+    assert np.allclose(v[4], [0, 0, 1.3, 0, 0, 0, 1, 10, 10, 0.05])     # ceiling
+    assert np.allclose(v[5], [0, 0, 0.0, 0, 0, 0, 1, 10, 10, 0.05])     # ground
+    assert np.allclose(v[6], [1.0, 0, 0.35, 0, 0, 0, 1, 0.05, 2.0, 0.7])
+    assert np.allclose(v[9], [0, -1.0, 0.35, 0, 0, 0, 1, 2.0, 0.05, 0.7])
+    assert mp.vertical_gap_scene(0.5, 0.5, 0.7, False).shape == (4, 10)

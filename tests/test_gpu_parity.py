@@ -80,3 +80,244 @@ def test_hydrus4_vs_oracle():
     w = common.config2(n=8000, n_links=4, n_boxes=40)
     r = check_against_oracle(w, 8000)
     print("hydrus4:", r)
+
+
+# ---------------------------------------------------------------------------
+# committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py)
+# ---------------------------------------------------------------------------
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+GOLD_CASES = {
+    "c2_hydrus6_se2": lambda: common.config2(n=8),
+    "c2_hydrus6_se3": lambda: common.config2(n=8, orient="so3"),
+    "c3_dragon4": lambda: common.config3(n=8),
+    "c5_hydrus8": lambda: common.config5(n=8, n_boxes=200),
+    "c1_hydrus4": lambda: common.config2(n=8, n_links=4, n_boxes=30),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GOLD_CASES))
+def test_gpu_matches_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    w = GOLD_CASES[name]()
+    eng = mp.Engine(w.model, g["boxes"], w.params)
+    fast = eng.is_valid_batch(g["soa"], w.layout)["flags"]
+    full = eng.eval_batch(g["soa"], w.layout)
+    eng.close()
+    band = (g["band"] | full["band"]).astype(bool)
+    assert not np.any((fast != g["flags"]) & ~band)
+    assert not np.any((full["flags"] != g["flags"]) & ~band)
+    fin = np.isfinite(g["min_dist"])
+    assert np.all(_close(full["min_dist"][fin], g["min_dist"][fin]))
+    well = g["pivot_ratio"] > 1e-9
+    assert np.all(_close(full["margin"][well], g["margin"][well]))
+    # band flags themselves agree except where the deciding quantity sits within rounding of +-eps
+    near = (np.abs(np.abs(g["min_dist"]) - 1e-6) < 1e-9) | (np.abs(np.abs(g["margin"]) - 1e-6) < 1e-9)
+    assert np.array_equal(full["band"][~near], g["band"][~near])
+
+
+# ---------------------------------------------------------------------------
+# motion validation (DiscreteMotionValidator::checkMotion, motion_planning.cpp:238,249)
+# ---------------------------------------------------------------------------
+def _edge_compare(ok, first, g_ok, g_first, band):
+    diff = (ok != g_ok) | (first != g_first)
+    assert not np.any(diff & ~band.astype(bool)), f"{np.sum(diff & ~band.astype(bool))} edge mismatches outside the band"
+
+
+def test_edges_uniform_nd64_and_variable_nd_match_golden():
+    g = np.load(os.path.join(GOLD, "c4_edges.npz"))
+    model, params, _, _, _, _ = common.config4(n_edges=4)
+    eng = mp.Engine(model, g["boxes"], params)
+    ok, first = eng.check_motion_batch(g["s1"], g["s2"], int(g["nd"]))
+    _edge_compare(ok, first, g["ok"], g["first"], g["band"])
+    assert np.array_equal(ok == 1, first == int(g["nd"]) + 1)
+    ok, first = eng.check_motion_batch(g["s1"], g["s2"], g["nd_var"])
+    _edge_compare(ok, first, g["ok_var"], g["first_var"], g["band_var"])
+    eng.close()
+
+
+@pytest.mark.parametrize("kind,mode,mt", [("hydrus", 0, 0), ("hydrus", 1, 0), ("hydrus", 2, 0), ("dragon", 1, 1), ("dragon", 2, 1)])
+def test_edges_all_modes_vs_oracle(kind, mode, mt):
+    rng = np.random.default_rng(100 + 10 * mode + mt)
+    model = mp.make_model(kind, 4)
+    params = mp.default_params(model, mode, mt)
+    J = model.n_joint
+    boxes = common.random_boxes(rng, 30, [-2, -2, -1], [2, 2, 1.5], 0.05, 0.3, "so3")
+    E = 300
+    sp = O.Space(params, J)
+
+    def sample(n):
+        rows = []
+        if mode != 0:
+            if mt == 0:
+                rows += [rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(-np.pi, np.pi, n)]
+            else:
+                rows += list(rng.uniform(-1.5, 1.5, (3, n))) + list(common.random_unit_quats(rng, n))
+        if mode != 1:
+            rows += list(rng.uniform(-1.58, 1.58, (J, n)))
+        return np.array(rows)
+    s1, s2 = sample(E), sample(E)
+    s2 = s1 + 0.15 * (s2 - s1)
+    if mode != 0 and mt == 1:
+        s2[3:7] /= np.linalg.norm(s2[3:7], axis=0)
+    nd = np.array([max(1, min(200, sp.valid_segment_count(s1[:, e], s2[:, e]))) for e in range(E)], np.int32)
+    g_ok, g_first, g_band = O.check_motion_batch(model, boxes, params, s1, s2, nd)
+    eng = mp.Engine(model, boxes, params)
+    ok, first = eng.check_motion_batch(s1, s2, nd)
+    eng.close()
+    _edge_compare(ok, first, g_ok, g_first, g_band)
+
+
+# ---------------------------------------------------------------------------
+# layouts, modes, edge cases
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,mt", [(0, 0), (1, 0), (1, 1), (2, 0), (2, 1)])
+def test_modes_and_ompl_layout_vs_oracle(mode, mt):
+    rng = np.random.default_rng(40 + 2 * mode + mt)
+    model = mp.make_model("hydrus", 4)
+    params = mp.default_params(model, mode, mt)
+    boxes = common.random_boxes(rng, 25, [-2, -2, -1], [3, 2, 1], 0.05, 0.4, "yaw")
+    n = 3000
+    rows = []
+    if mode != 0:
+        if mt == 0:
+            rows += [rng.uniform(-2, 5, n), rng.uniform(-2.2, 2.2, n), rng.uniform(-4, 4, n)]
+        else:
+            rows += list(rng.uniform(-2, 2, (3, n))) + list(common.random_unit_quats(rng, n) * rng.uniform(0.5, 2.0, n))
+    if mode != 1:
+        rows += list(rng.uniform(-1.58, 1.58, (3, n)))
+    s = np.array(rows)
+    ref = O.eval_batch(model, boxes, params, s, A.LAYOUT_OMPL, threads=8)
+    eng = mp.Engine(model, boxes, params)
+    got = eng.is_valid_batch(s, A.LAYOUT_OMPL, want=("flags", "min_dist", "margin", "band"))
+    fast = eng.is_valid_batch(s, A.LAYOUT_OMPL)["flags"]
+    r0 = eng.is_valid(s[:, 0])
+    eng.close()
+    band = (ref["band"] | got["band"]).astype(bool)
+    assert not np.any((got["flags"] != ref["flags"]) & ~band)
+    assert not np.any((fast != ref["flags"]) & ~band)
+    fin = np.isfinite(ref["min_dist"])
+    assert np.array_equal(fin, np.isfinite(got["min_dist"]))
+    assert np.all(_close(got["min_dist"][fin], ref["min_dist"][fin]))
+    assert r0.valid == ref["flags"][0] and r0.collision == ref["collision"][0]
+
+
+def test_ragged_sizes_empty_scene_and_bad_inputs():
+    w = common.config2(n=1000)
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    ref = O.eval_batch(w.model, w.boxes, w.params, w.soa, w.layout, threads=8)
+    for n in (1, 63, 64, 65, 255, 257, 1000):
+        f = eng.is_valid_batch(w.soa[:, :n], w.layout)["flags"]
+        assert np.array_equal(f, ref["flags"][:n]), n
+    # n = 0 is a no-op
+    assert len(eng.is_valid_batch(w.soa[:, :0], w.layout)["flags"]) == 0
+    # non-finite states and zero quaternions: invalid + band, never a fault
+    bad = w.soa[:, :256].copy()
+    bad[8, 3] = np.nan
+    bad[0, 7] = np.inf
+    bad[3:7, 11] = 0.0
+    out = eng.is_valid_batch(bad, w.layout, want=("flags", "band", "min_dist", "margin"))
+    for i in (3, 7, 11):
+        assert out["flags"][i] == 0 and out["band"][i] == 1
+    ok = np.ones(256, bool)
+    ok[[3, 7, 11]] = False
+    assert np.array_equal(out["flags"][ok], ref["flags"][:256][ok])
+    # empty world: nothing collides, min distance is +inf
+    eng.set_scene(np.zeros((0, 10)))
+    out = eng.is_valid_batch(w.soa[:, :500], w.layout, want=("flags", "min_dist"))
+    assert np.all(np.isinf(out["min_dist"])) and np.array_equal(out["flags"], ref["stable"][:500])
+    # argument errors come back as codes, not crashes
+    with pytest.raises(mp.MvkError):
+        eng.set_scene(np.array([[0, 0, 0, 0, 0, 0, 0, 1, 1, 1.0]]))   # zero quaternion obstacle
+    eng.close()
+
+
+def test_candidate_list_overflow_falls_back_to_full_sweep():
+    """more than 24 boxes around one primitive: the per-lane list overflows and the kernel must still be exact"""
+    rng = np.random.default_rng(9)
+    model = mp.make_model("hydrus", 4)
+    params = mp.default_params(model, A.MODE_JOINTS_AND_BASE, A.SE2)
+    m = 120
+    boxes = np.zeros((m, 10))
+    ang = rng.uniform(np.deg2rad(215), np.deg2rad(325), m)   # the -y side: clear of the other links of the square
+    rad = rng.uniform(0.235, 0.40, m)              # a shell of tiny boxes around link1's protector
+    boxes[:, 0] = 0.3 + rad * np.cos(ang)
+    boxes[:, 1] = rad * np.sin(ang)
+    boxes[:, 2] = rng.uniform(-0.05, 0.15, m)
+    boxes[:, 3:7] = common.random_unit_quats(rng, m).T
+    boxes[:, 7:10] = rng.uniform(0.01, 0.04, (m, 3))
+    n = 512
+    s = np.zeros((10, n))
+    s[0] = rng.uniform(-0.02, 0.02, n)
+    s[1] = rng.uniform(-0.02, 0.02, n)
+    s[6] = 1.0
+    s[7:] = 1.57 + rng.uniform(-0.02, 0.02, (3, n))
+    ref = O.eval_batch(model, boxes, params, s, threads=8)
+    eng = mp.Engine(model, boxes, params)
+    got = eng.eval_batch(s)
+    fast = eng.is_valid_batch(s)["flags"]
+    eng.close()
+    band = (ref["band"] | got["band"]).astype(bool)
+    assert not np.any((fast != ref["flags"]) & ~band) and not np.any((got["flags"] != ref["flags"]) & ~band)
+    assert np.all(_close(got["min_dist"], ref["min_dist"]))
+    assert 0 < ref["flags"].sum() < n   # the case is not degenerate
+
+
+# ---------------------------------------------------------------------------
+# BASELINE sizes: size-independent properties (the oracle cannot sweep 1M samples in seconds)
+# ---------------------------------------------------------------------------
+def test_full_size_c2_properties():
+    import torch
+    n = 1 << 20
+    w = common.config2(n=n)
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    dev = torch.device("cuda", 0)
+    d = torch.from_numpy(w.soa).to(dev)
+    flags = torch.zeros(n, dtype=torch.uint8, device=dev)
+    mask = torch.zeros(n // 64, dtype=torch.int64, device=dev)
+    eng.is_valid_batch_dev(d, w.layout, d_flags=flags)
+    eng.is_valid_mask_dev(d, w.layout, mask)
+    torch.cuda.synchronize()
+    f = flags.cpu().numpy()
+    bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")
+    assert np.array_equal(bits, f)                       # packed mask == byte flags
+    # idempotence: same launch again gives the same bits
+    flags2 = torch.zeros_like(flags)
+    eng.is_valid_batch_dev(d, w.layout, d_flags=flags2)
+    torch.cuda.synchronize()
+    assert torch.equal(flags, flags2)
+    # permutation equivariance: a permuted batch gives permuted flags (no cross-lane leakage)
+    perm = torch.randperm(n, device=dev)
+    dp = d[:, perm].contiguous()
+    eng.is_valid_batch_dev(dp, w.layout, d_flags=flags2)
+    torch.cuda.synchronize()
+    assert torch.equal(flags[perm], flags2)
+    # full kernel agrees with the flag kernel outside its own band; collision <=> min_dist <= 0
+    md = torch.zeros(n, dtype=torch.float64, device=dev)
+    mg = torch.zeros(n, dtype=torch.float64, device=dev)
+    bd = torch.zeros(n, dtype=torch.uint8, device=dev)
+    eng.is_valid_batch_dev(d, w.layout, d_flags=flags2, d_min_dist=md, d_margin=mg, d_band=bd)
+    torch.cuda.synchronize()
+    st = eng.reduce_stats()
+    inb = bd.bool()
+    assert torch.equal(flags[~inb], flags2[~inb])
+    assert torch.equal(flags2.bool(), (md > 0) & (mg >= 0))
+    assert st["valid_count"] == int(flags2.sum()) and st["min_dist"] == float(md.min())
+    # a slice against the oracle
+    k = 4096
+    ref = O.flags_only(w.model, w.boxes, w.params, w.soa[:, -k:], w.layout, threads=8)
+    assert np.array_equal(ref, f[-k:]) or np.all(bd.cpu().numpy()[-k:][ref != f[-k:]] == 1)
+    # translating world and robot together changes nothing (up to the band)
+    shift = np.array([0.37, -0.21, 0.11])
+    w2 = w.soa.copy()
+    w2[0:3] += shift[:, None]
+    b2 = w.boxes.copy()
+    b2[:, 0:3] += shift
+    eng.set_scene(b2)
+    eng.is_valid_batch_dev(torch.from_numpy(w2).to(dev), w.layout, d_flags=flags2)
+    torch.cuda.synchronize()
+    changed = (flags2 != flags).cpu().numpy()
+    assert changed.sum() <= 20, changed.sum()            # only samples within rounding of contact may flip
+    assert np.all(np.abs(md.cpu().numpy()[changed]) < 1e-9)
+    eng.close()
