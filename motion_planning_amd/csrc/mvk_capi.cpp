@@ -77,8 +77,10 @@ struct mvk_ctx {
   DevExtras extras{};
   mvk_model* d_model = nullptr;
   DevExtras* d_extras = nullptr;
-  Buf obs;
+  Buf obs, obsf;
   int n_obs = 0;
+  float f32_delta = 0.0f;
+  double f32_range = 0.0;
   hipStream_t stream = nullptr;
   // staging for the host-pointer entry points
   Buf in_a, in_b, flags, band, mind, margin, det[6], nd, ok, first, edge_off;
@@ -129,6 +131,43 @@ void derive_extras(const mvk_model* m, DevExtras* x) {
       if (m->prim_seg[q] == k) x->prim_order[at++] = q;
   }
   for (int k = m->n_seg; k <= MVK_MAX_SEG; ++k) x->seg_prim_begin[k] = at;
+  // bounding sphere of each segment's primitives (level-1 cull) and the robot's reach
+  double chain = 0.0;
+  x->reach = 0.0;
+  std::vector<double> bound(m->n_prim);
+  for (int q = 0; q < m->n_prim; ++q) {
+    const double* d = m->prim_dim[q];
+    bound[q] = m->prim_type[q] == MVK_PRIM_SPHERE ? d[0]
+               : m->prim_type[q] == MVK_PRIM_CAPSULE ? d[0] + d[1]
+                                                      : std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  }
+  auto norm3 = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+  for (int k = 0; k < m->n_seg; ++k) {
+    if (k > 0) chain += norm3(m->seg_t[k]);
+    double c[3] = {0, 0, 0};
+    int cntk = 0;
+    auto anchor = [&](int q) { return m->prim_frame[q] == MVK_FRAME_SEG ? m->prim_pos[q] : m->rotor_pos[m->prim_rotor[q]]; };
+    for (int q = 0; q < m->n_prim; ++q)
+      if (m->prim_seg[q] == k) {
+        for (int a = 0; a < 3; ++a) c[a] += anchor(q)[a];
+        ++cntk;
+      }
+    double r = 0.0;
+    if (cntk) {
+      for (int a = 0; a < 3; ++a) c[a] /= cntk;
+      for (int q = 0; q < m->n_prim; ++q)
+        if (m->prim_seg[q] == k) {
+          const double* an = anchor(q);
+          const double dd[3] = {an[0] - c[0], an[1] - c[1], an[2] - c[2]};
+          // a primitive on a gimbal frame swings about the gimbal centre by |prim_pos|
+          const double ext = bound[q] + (m->prim_frame[q] == MVK_FRAME_SEG ? 0.0 : norm3(m->prim_pos[q]));
+          r = std::fmax(r, norm3(dd) + ext);
+        }
+      x->reach = std::fmax(x->reach, chain + norm3(c) + r);
+    }
+    x->seg_sph[k][0] = c[0]; x->seg_sph[k][1] = c[1]; x->seg_sph[k][2] = c[2];
+    x->seg_sph[k][3] = r * (1.0 + 1e-12) + 1e-12;
+  }
   for (int q = 0; q < m->n_prim; ++q) {
     const double* d = m->prim_dim[q];
     switch (m->prim_type[q]) {
@@ -157,9 +196,28 @@ int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
       if (!std::isfinite(o.R[k])) return fail(MVK_ERR_INVALID_ARG, "obstacle %zu: invalid quaternion", i);
     o.bound = std::sqrt(o.h[0] * o.h[0] + o.h[1] * o.h[1] + o.h[2] * o.h[2]);
   }
+  // fp32 copy for the level-1 cull, and the coordinate range / error bound it is trusted for:
+  // every fp32 rounding in the centre-distance evaluation is <= 2^-24 relative to a coordinate
+  // difference of at most 2*range; the accumulated bound on the distance error is < 4e-6 * range.
+  std::vector<DevObsF> hostf(n);
+  double range = 64.0;
+  for (size_t i = 0; i < n; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      hostf[i].c[k] = static_cast<float>(host[i].c[k]);
+      hostf[i].h[k] = static_cast<float>(host[i].h[k]);
+      range = std::fmax(range, std::fabs(host[i].c[k]) + host[i].bound);
+    }
+    for (int k = 0; k < 9; ++k) hostf[i].R[k] = static_cast<float>(host[i].R[k]);
+    hostf[i].pad = 0.0f;
+  }
+  if (!(range < 1e6)) return fail(MVK_ERR_INVALID_ARG, "obstacle coordinates beyond 1e6 m");
   if (int rc = c->obs.reserve(sizeof(DevObs) * (n ? n : 1))) return rc;
+  if (int rc = c->obsf.reserve(sizeof(DevObsF) * (n ? n : 1))) return rc;
   if (n) HIP_TRY(hipMemcpy(c->obs.p, host.data(), sizeof(DevObs) * n, hipMemcpyHostToDevice));
+  if (n) HIP_TRY(hipMemcpy(c->obsf.p, hostf.data(), sizeof(DevObsF) * n, hipMemcpyHostToDevice));
   c->n_obs = static_cast<int>(n);
+  c->f32_range = range;
+  c->f32_delta = static_cast<float>(4e-6 * range);
   return MVK_OK;
 }
 
@@ -191,6 +249,9 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
   a.model = c->d_model;
   a.extras = c->d_extras;
   a.obs = static_cast<const DevObs*>(c->obs.p);
+  a.obsf = static_cast<const DevObsF*>(c->obsf.p);
+  a.f32_delta = c->f32_delta;
+  a.f32_range = c->f32_range;
   a.n_obs = c->n_obs;
   a.nd_uniform = 1;
 }
@@ -322,7 +383,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
   }
   if (c->d_model) (void)hipFree(c->d_model);
   if (c->d_extras) (void)hipFree(c->d_extras);
-  Buf* all[] = {&c->obs, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
+  Buf* all[] = {&c->obs, &c->obsf, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
                 &c->partial, &c->stats_out};
   for (Buf* b : all) b->release();

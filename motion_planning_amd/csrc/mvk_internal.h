@@ -23,6 +23,14 @@ struct DevObs {
   double bound;  // circumscribed-sphere radius
 };
 
+// fp32 copy for the level-1 cull: 16 floats = 64 B = one s_load_dwordx16.
+struct DevObsF {
+  float c[3];
+  float R[9];
+  float h[3];
+  float pad;
+};
+
 // Model constants derived once on the host.
 struct DevExtras {
   double tan_edf_max_tilt;
@@ -30,6 +38,8 @@ struct DevExtras {
   double prim_inner[MVK_MAX_PRIM];  // radius about the origin contained in it
   int32_t seg_prim_begin[MVK_MAX_SEG + 1];  // primitives sorted by segment
   int32_t prim_order[MVK_MAX_PRIM];
+  double seg_sph[MVK_MAX_SEG][4];  // per segment: sphere (centre in the segment frame, radius) holding its primitives
+  double reach;                    // bound on the distance of any primitive point from the root origin
 };
 
 struct SpaceDev {  // what in-kernel interpolation needs
@@ -56,7 +66,10 @@ struct EvalArgs {
   const mvk_model* model;
   const DevExtras* extras;
   const DevObs* obs;
+  const DevObsF* obsf;
   int32_t n_obs;
+  float f32_delta;   // bound on the fp32 centre-distance error inside f32_range [m]
+  double f32_range;  // coordinate magnitude up to which f32_delta holds
   // outputs (nullable)
   uint8_t* flags;
   uint64_t* mask;

@@ -248,7 +248,7 @@ struct Shape {
   static constexpr int rotor_seg(int i) { return kGimbal ? 2 * i : i; }
 };
 
-constexpr int kListCap = 24;  // per-lane narrowphase candidates per primitive
+constexpr int kListCap = 32;  // per-lane narrowphase candidates per primitive
 
 struct Smem {
   // [2*J][kBlock] cos/sin of the planned joints, lane-contiguous
@@ -273,7 +273,8 @@ DEV void gimbal_cs(double zlx, double zly, double zlz, double& cr, double& sr, d
 
 template <int ROBOT, int NL, bool FULL>
 DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
-                    const DevObs* __restrict__ obs, const double st[7 + Shape<ROBOT, NL>::kJoint],
+                    const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf,
+                    const double st[7 + Shape<ROBOT, NL>::kJoint],
                     const Smem& sm, uint64_t gi, StateOut& out, double* thrust_out /*[NL] or nullptr*/) {
   using S = Shape<ROBOT, NL>;
   constexpr int NS = S::kSeg, NJ = S::kJoint, D = S::kDof;
@@ -515,6 +516,8 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
   // lanes that cannot change their verdict any more stop generating work
   bool live = finite && A.do_coll && (FULL || !A.do_stab || out.stable);
   double mind = INFINITY;  // running exact minimum (FULL) / <= 0 once a hit is found
+  // the fp32 segment cull is only trusted while every coordinate stays inside f32_range
+  const bool f32_safe = fmax(fabs(st[0]), fmax(fabs(st[1]), fabs(st[2]))) + X->reach <= A.f32_range;
   if (A.do_coll && A.n_obs > 0 && __any(live)) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = Rw[k];
@@ -529,11 +532,8 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
         const double c = sm.cs[(2 * jn) * kBlock + tid], s = sm.cs[(2 * jn + 1) * kBlock + tid];
         rot_cols_dyn(R, M->seg_axis[k], c, s);
       }
-#pragma unroll 1
-      for (int qi = X->seg_prim_begin[k]; qi < X->seg_prim_begin[k + 1]; ++qi) {
-        const int q = X->prim_order[qi];
-        const int type = M->prim_type[q];
-        // pose of the primitive: base frame * collision origin
+      // pose of primitive q riding on the current segment frame (R, p)
+      auto prim_pose = [&](int q, double pc[3], double PR[9]) {
         double B[9], bp[3];
 #pragma unroll
         for (int e = 0; e < 9; ++e) B[e] = R[e];
@@ -548,15 +548,134 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
           rot_cols<0>(B, cr, sr);
           if (M->prim_frame[q] == MVK_FRAME_GIMBAL_PITCH) rot_cols<1>(B, cp, sp);
         }
-        double pc[3], PR[9];
         xform(B, bp, M->prim_pos[q][0], M->prim_pos[q][1], M->prim_pos[q][2], pc);
-        {
-          double Lr[9];
+        double Lr[9];
 #pragma unroll
-          for (int e = 0; e < 9; ++e) Lr[e] = M->prim_rot[q][e];
-          mat_mul(B, Lr, PR);
+        for (int e = 0; e < 9; ++e) Lr[e] = M->prim_rot[q][e];
+        mat_mul(B, Lr, PR);
+      };
+      // exact signed test of one primitive against one box (kind is wave-uniform)
+      auto narrow = [&](int type, const double pc[3], const double PR[9], double d0, double d1, double d2,
+                        const DevObs& O, const double t[3]) -> double {
+        double d;
+        if (type == MVK_PRIM_CAPSULE) {
+          // axis = local z in world = third column of PR, into the box frame
+          double a[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a[c] = fma(O.R[c], PR[2], fma(O.R[3 + c], PR[5], O.R[6 + c] * PR[8]));
+          double p0[3], dd[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { p0[c] = fma(-d1, a[c], t[c]); dd[c] = 2.0 * d1 * a[c]; }
+          const double s2 = seg_box_dist2(p0, dd, O.h);
+          if (FULL) d = sqrt(s2) - d0;
+          else d = (s2 <= d0 * d0) ? 0.0 : 1.0;
+        } else {
+          // box: primitive axes in the obstacle frame  Rr = O.R^T * PR
+          double Rr[9];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              Rr[3 * r + c] = fma(O.R[r], PR[c], fma(O.R[3 + r], PR[3 + c], O.R[6 + r] * PR[6 + c]));
+          const double a[3] = {d0, d1, d2};
+          if (FULL) {
+            d = box_box_sat<true>(t, Rr, a, O.h);
+            if (d > 0.0) {
+              // exact separation: closest features always include a point on an edge
+              double s2 = box_edges_to_box2(t, Rr, a, O.h);
+              double Rt[9], tb[3];  // obstacle in the primitive's frame
+#pragma unroll
+              for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Rt[3 * r + c] = Rr[3 * c + r];
+#pragma unroll
+              for (int r = 0; r < 3; ++r) tb[r] = -fma(Rr[r], t[0], fma(Rr[3 + r], t[1], Rr[6 + r] * t[2]));
+              s2 = fmin(s2, box_edges_to_box2(tb, Rt, O.h, a));
+              d = sqrt(s2);
+            }
+          } else {
+            d = box_box_sat<false>(t, Rr, a, O.h);
+          }
         }
-        const double rb = X->prim_bound[q], rin = X->prim_inner[q];
+        return d;
+      };
+      auto to_box_frame = [&](const DevObs& O, const double pc[3], double t[3]) {
+        const double dx = pc[0] - O.c[0], dy = pc[1] - O.c[1], dz = pc[2] - O.c[2];
+        t[0] = fma(O.R[0], dx, fma(O.R[3], dy, O.R[6] * dz));
+        t[1] = fma(O.R[1], dx, fma(O.R[4], dy, O.R[7] * dz));
+        t[2] = fma(O.R[2], dx, fma(O.R[5], dy, O.R[8] * dz));
+      };
+      const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
+
+      if (!FULL) {
+        // ===== flag path: two-level cull =====================================
+        // level 1 (fp32, wave-uniform obstacle reads): one bounding sphere per segment
+        // against every box; survivors go to this lane's LDS list.  The fp32 test is
+        // conservative: its radius is inflated by f32_delta, a bound on the fp32
+        // evaluation error for coordinates within f32_range (lanes outside that range
+        // keep every box).  level 2 (fp64, per lane): exact centre test + narrowphase
+        // of each primitive of the segment against the listed boxes only.
+        if (pb == pe) continue;
+        double sc[3];
+        xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
+        const float sx = static_cast<float>(sc[0]), sy = static_cast<float>(sc[1]), sz = static_cast<float>(sc[2]);
+        const float thr = (static_cast<float>(X->seg_sph[k][3]) + A.f32_delta) * 1.000001f;
+        const float thr2 = f32_safe ? thr * thr : INFINITY;
+        int cnt = 0;
+#pragma unroll 2
+        for (int ob = 0; ob < A.n_obs; ++ob) {
+          const DevObsF& F = obsf[ob];  // 64 B, one s_load_dwordx16
+          const float dx = sx - F.c[0], dy = sy - F.c[1], dz = sz - F.c[2];
+          const float e0 = fmaxf(fabsf(fmaf(F.R[0], dx, fmaf(F.R[3], dy, F.R[6] * dz))) - F.h[0], 0.0f);
+          const float e1 = fmaxf(fabsf(fmaf(F.R[1], dx, fmaf(F.R[4], dy, F.R[7] * dz))) - F.h[1], 0.0f);
+          const float e2 = fmaxf(fabsf(fmaf(F.R[2], dx, fmaf(F.R[5], dy, F.R[8] * dz))) - F.h[2], 0.0f);
+          const float l2 = fmaf(e0, e0, fmaf(e1, e1, e2 * e2));
+          if (live && l2 <= thr2) {
+            if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
+            ++cnt;
+          }
+        }
+        const bool overflow = cnt > kListCap;  // fall back to testing every box for this segment
+        const int ntodo = live ? (overflow ? A.n_obs : cnt) : 0;
+        if (__any(ntodo > 0)) {
+#pragma unroll 1
+          for (int qi = pb; qi < pe; ++qi) {
+            const int q = X->prim_order[qi];
+            const int type = M->prim_type[q];
+            double pc[3], PR[9];
+            prim_pose(q, pc, PR);
+            const double rb = X->prim_bound[q], rin = X->prim_inner[q];
+            const double rb2 = rb * rb, rin2 = rin * rin;
+            const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+            int todo = live ? ntodo : 0;
+#pragma unroll 1
+            for (int e = 0; __any(e < todo); ++e) {
+              if (e < todo) {
+                const int ob = overflow ? e : sm.list[e * kBlock + tid];
+                const DevObs O = obs[ob];
+                double t[3];
+                to_box_frame(O, pc, t);
+                const double e0 = excess_abs(t[0], O.h[0]), e1 = excess_abs(t[1], O.h[1]), e2 = excess_abs(t[2], O.h[2]);
+                const double l2 = fma(e0, e0, fma(e1, e1, e2 * e2));
+                bool hit = l2 <= rin2;  // a ball inside the primitive already touches the box
+                if (!hit && type != MVK_PRIM_SPHERE && l2 <= rb2) hit = narrow(type, pc, PR, d0, d1, d2, O, t) <= 0.0;
+                if (hit) { mind = 0.0; live = false; todo = 0; }
+              }
+            }
+          }
+        }
+        if (!__any(live)) break;
+        continue;
+      }
+
+      // ===== full path: exact minimum distance over every (primitive, box) pair =====
+#pragma unroll 1
+      for (int qi = pb; qi < pe; ++qi) {
+        const int q = X->prim_order[qi];
+        const int type = M->prim_type[q];
+        double pc[3], PR[9];
+        prim_pose(q, pc, PR);
+        const double rb = X->prim_bound[q];
         const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
 
         // -- broadphase sweep: centre-to-box distance vs bounding radius -------
@@ -569,45 +688,29 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
           return fma(e0, e0, fma(e1, e1, e2 * e2));
         };
         int cnt = 0;
-        if (FULL) {
-          // pass 1: the primitive's origin lies inside it, so min_ob dist(origin, box)
-          // bounds this primitive's separation from above
-          double best2 = INFINITY;
+        // pass 1: the primitive's origin lies inside it, so min_ob dist(origin, box)
+        // bounds this primitive's separation from above
+        double best2 = INFINITY;
 #pragma unroll 2
-          for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
-          if (type == MVK_PRIM_SPHERE) {
-            mind = fmin(mind, sqrt(best2) - d0);  // exact for a sphere
-          } else {
-            // pass 2: keep pairs whose lower bound (centre distance - bounding radius)
-            // can still undercut the running minimum, and every possibly-touching pair
-            const double thr = rb + fmax(fmin(mind, sqrt(best2)), 0.0);
-            const double thr2 = thr * thr;
-#pragma unroll 2
-            for (int ob = 0; ob < A.n_obs; ++ob) {
-              if (live && centre_dist2(obs[ob]) <= thr2) {
-                if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
-                ++cnt;
-              }
-            }
-          }
+        for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
+        if (type == MVK_PRIM_SPHERE) {
+          mind = fmin(mind, sqrt(best2) - d0);  // exact for a sphere
         } else {
-          const double rb2 = rb * rb, rin2 = rin * rin;
-          bool hit = false;
+          // pass 2: keep pairs whose lower bound (centre distance - bounding radius)
+          // can still undercut the running minimum, and every possibly-touching pair
+          const double thr = rb + fmax(fmin(mind, sqrt(best2)), 0.0);
+          const double thr2 = thr * thr;
 #pragma unroll 2
           for (int ob = 0; ob < A.n_obs; ++ob) {
-            const double l2 = centre_dist2(obs[ob]);
-            hit = hit || (l2 <= rin2);  // a ball inside the primitive already touches the box
-            if (type != MVK_PRIM_SPHERE && live && l2 <= rb2 && l2 > rin2) {
+            if (live && centre_dist2(obs[ob]) <= thr2) {
               if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
               ++cnt;
             }
           }
-          if (hit && live) mind = fmin(mind, 0.0);
         }
-
         // -- narrowphase drain: kind is wave-uniform, list length is per lane ---
         const bool overflow = cnt > kListCap;
-        int todo = (live && (FULL || !(mind <= 0.0))) ? (overflow ? A.n_obs : cnt) : 0;
+        int todo = live ? (overflow ? A.n_obs : cnt) : 0;
         if (type == MVK_PRIM_SPHERE) todo = 0;
 #pragma unroll 1
         for (int e = 0; __any(e < todo); ++e) {
@@ -616,63 +719,11 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
             const int ob = overflow ? e : sm.list[e * kBlock + tid];
             const DevObs O = obs[ob];
             double t[3];
-            {
-              const double dx = pc[0] - O.c[0], dy = pc[1] - O.c[1], dz = pc[2] - O.c[2];
-              t[0] = fma(O.R[0], dx, fma(O.R[3], dy, O.R[6] * dz));
-              t[1] = fma(O.R[1], dx, fma(O.R[4], dy, O.R[7] * dz));
-              t[2] = fma(O.R[2], dx, fma(O.R[5], dy, O.R[8] * dz));
-            }
-            double d;
-            if (type == MVK_PRIM_CAPSULE) {
-              // axis = local z in world = third column of PR, into the box frame
-              double a[3];
-#pragma unroll
-              for (int c = 0; c < 3; ++c) a[c] = fma(O.R[c], PR[2], fma(O.R[3 + c], PR[5], O.R[6 + c] * PR[8]));
-              double p0[3], dd[3];
-#pragma unroll
-              for (int c = 0; c < 3; ++c) { p0[c] = fma(-d1, a[c], t[c]); dd[c] = 2.0 * d1 * a[c]; }
-              const double s2 = seg_box_dist2(p0, dd, O.h);
-              if (FULL) d = sqrt(s2) - d0;
-              else d = (s2 <= d0 * d0) ? 0.0 : 1.0;
-            } else {
-              // box: primitive axes in the obstacle frame  Rr = O.R^T * PR
-              double Rr[9];
-#pragma unroll
-              for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                  Rr[3 * r + c] = fma(O.R[r], PR[c], fma(O.R[3 + r], PR[3 + c], O.R[6 + r] * PR[6 + c]));
-              const double a[3] = {d0, d1, d2};
-              if (FULL) {
-                d = box_box_sat<true>(t, Rr, a, O.h);
-                if (d > 0.0) {
-                  // exact separation: closest features always include a point on an edge
-                  double s2 = box_edges_to_box2(t, Rr, a, O.h);
-                  // obstacle in the primitive's frame
-                  double Rt[9], tb[3];
-#pragma unroll
-                  for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) Rt[3 * r + c] = Rr[3 * c + r];
-#pragma unroll
-                  for (int r = 0; r < 3; ++r) tb[r] = -fma(Rr[r], t[0], fma(Rr[3 + r], t[1], Rr[6 + r] * t[2]));
-                  s2 = fmin(s2, box_edges_to_box2(tb, Rt, O.h, a));
-                  d = sqrt(s2);
-                }
-              } else {
-                d = box_box_sat<false>(t, Rr, a, O.h);
-              }
-            }
-            mind = fmin(mind, d);
-            if (!FULL && d <= 0.0) todo = 0;  // verdict reached
+            to_box_frame(O, pc, t);
+            mind = fmin(mind, narrow(type, pc, PR, d0, d1, d2, O, t));
           }
         }
-        if (!FULL) {
-          live = live && !(mind <= 0.0);
-          if (!__any(live)) break;
-        }
       }
-      if (!FULL && !__any(live)) break;
     }
   }
   out.min_dist = (A.do_coll && finite) ? mind : INFINITY;
@@ -734,7 +785,7 @@ DEV void unpack_ompl(const EvalArgs& A, const double* s, double* st) {
 template <int ROBOT, int NL, bool FULL, bool EDGE>
 __global__ void __launch_bounds__(kBlock)
 validity_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
-                const DevObs* __restrict__ obs) {
+                const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf) {
   using S = Shape<ROBOT, NL>;
   constexpr int NJ = S::kJoint;
   __shared__ double sm_cs[2 * NJ * kBlock];
@@ -820,7 +871,7 @@ validity_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
 
   StateOut o;
   double thrust[NL];
-  eval_state<ROBOT, NL, FULL>(A, M, X, obs, st, sm, li, o, FULL ? thrust : nullptr);
+  eval_state<ROBOT, NL, FULL>(A, M, X, obs, obsf, st, sm, li, o, FULL ? thrust : nullptr);
 
   if (!EDGE) {
     if (in_range) {
@@ -954,11 +1005,11 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s) {
   if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
   if (edge_mode) {
-    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, true>), g, b, 0, s, a, a.model, a.extras, a.obs);
+    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, true>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
   } else if (a.full) {
-    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, true, false>), g, b, 0, s, a, a.model, a.extras, a.obs);
+    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, true, false>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
   } else {
-    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, false>), g, b, 0, s, a, a.model, a.extras, a.obs);
+    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, false>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
   }
   return hipGetLastError();
 }
