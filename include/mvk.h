@@ -281,6 +281,68 @@ double mvk_space_max_extent(const mvk_params* p, int n_joint);
 /* the unpack of motion_planning.cpp:81-129: OMPL state -> px py pz qx qy qz qw j1..jJ */
 int mvk_space_unpack(const mvk_params* p, int n_joint, const double* s, double* pose7j);
 
+
+/* ---- planner ------------------------------------------ *
+ * Host-side RRT-Connect that drives the batched checker.  The reference plans
+ * with OMPL RRT* (motion_planning.cpp:391-408); BASELINE.json's metric asks for
+ * an RRT-Connect gap-pass solve time, so this is the build's own planner with
+ * OMPL's RRTConnect structure (two trees, extend by `range`, greedy connect),
+ * batched: every iteration grows `batch` random extensions with one edge-check
+ * launch and answers them with one connect launch. */
+typedef struct mvk_checker {
+  /* both callbacks return 0 on success; arrays are SoA in MVK_LAYOUT_OMPL */
+  int (*check_states)(void* user, const double* soa, size_t n, size_t ld, uint8_t* ok);
+  int (*check_motions)(void* user, const double* s1, const double* s2, size_t n_edges, size_t ld,
+                       const int32_t* nd, uint8_t* ok, int32_t* first_invalid);
+  void* user;
+} mvk_checker;
+
+typedef struct mvk_plan_request {
+  const double* start; /* MVK_LAYOUT_OMPL */
+  const double* goal;
+  double range;        /* max extension; <= 0: 0.2 * maximum extent (OMPL's default) */
+  double time_limit_s; /* solving_time_limit (motion_planning.cpp:530) */
+  uint64_t seed;
+  int32_t max_iterations; /* <= 0: unlimited */
+  int32_t batch;          /* extensions per iteration (>= 1) */
+} mvk_plan_request;
+
+typedef struct mvk_plan_result {
+  int32_t solved;
+  int32_t n_waypoints;
+  double solve_ms;      /* wall time of the search (planning_time of the log, in ms) */
+  double path_length;   /* sum of space distances along the way-points (motion_cost) */
+  uint64_t iterations, state_checks, edge_checks, edge_steps;
+  int32_t tree_sizes[2];
+} mvk_plan_result;
+
+/* generic form: validity through callbacks (lets the host logic run against any checker) */
+int mvk_plan_rrt_connect_cb(const mvk_params* params, int n_joint, const mvk_checker* checker,
+                            const mvk_plan_request* req, double* waypoints /*[cap][dim] row-major*/,
+                            int cap, mvk_plan_result* out);
+/* bound to the GPU context: MotionPlanning::plan (motion_planning.cpp:377-463) */
+int mvk_plan_rrt_connect(mvk_ctx* ctx, const mvk_plan_request* req, double* waypoints, int cap,
+                         mvk_plan_result* out);
+
+/* Solution densification exactly as motion_planning.cpp:424-446: for every pair of
+ * consecutive way-points addState(s1), the nd-1 interior states, addState(s2) -- so
+ * interior way-points appear twice, as in the reference's logs.  Returns the number of
+ * states written (row-major [n][dim]); negative on error / insufficient cap. */
+int mvk_path_densify(const mvk_params* params, int n_joint, const double* waypoints, int n_waypoints,
+                     double* states, int cap);
+
+/* Path log in the reference's text format (savePath/loadPath, motion_planning.cpp:644-800;
+ * SURVEY.md 6.1).  States are the unpacked px py pz qx qy qz qw j1..jJ rows. */
+typedef struct mvk_path_log {
+  int32_t n_states, n_joint, planning_mode;
+  double planning_time, motion_cost, minimum_var;
+  int32_t minimum_var_state_entry;
+  double start[MVK_MAX_STATE_DIM], goal[MVK_MAX_STATE_DIM];
+} mvk_path_log;
+int mvk_path_log_save(const char* file, const mvk_path_log* hdr, const double* states /*[n][7+J]*/);
+/* reads the header and up to cap states; returns the number of states in the file */
+int mvk_path_log_load(const char* file, int n_joint, mvk_path_log* hdr, double* states, int cap);
+
 #ifdef __cplusplus
 }
 #endif

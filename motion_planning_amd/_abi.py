@@ -72,6 +72,32 @@ class Stats(C.Structure):
                 ("min_rp_position_margin", d), ("min_rp_position_margin_index", C.c_int64)]
 
 
+CHECK_STATES_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_size_t, C.POINTER(C.c_uint8))
+CHECK_MOTIONS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_size_t,
+                               C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_int32))
+
+
+class Checker(C.Structure):
+    _fields_ = [("check_states", CHECK_STATES_FN), ("check_motions", CHECK_MOTIONS_FN), ("user", C.c_void_p)]
+
+
+class PlanRequest(C.Structure):
+    _fields_ = [("start", C.POINTER(C.c_double)), ("goal", C.POINTER(C.c_double)), ("range", d), ("time_limit_s", d),
+                ("seed", C.c_uint64), ("max_iterations", i32), ("batch", i32)]
+
+
+class PlanResult(C.Structure):
+    _fields_ = [("solved", i32), ("n_waypoints", i32), ("solve_ms", d), ("path_length", d),
+                ("iterations", C.c_uint64), ("state_checks", C.c_uint64), ("edge_checks", C.c_uint64),
+                ("edge_steps", C.c_uint64), ("tree_sizes", i32 * 2)]
+
+
+class PathLog(C.Structure):
+    _fields_ = [("n_states", i32), ("n_joint", i32), ("planning_mode", i32),
+                ("planning_time", d), ("motion_cost", d), ("minimum_var", d), ("minimum_var_state_entry", i32),
+                ("start", d * MAX_STATE_DIM), ("goal", d * MAX_STATE_DIM)]
+
+
 vp, sz, ip = C.c_void_p, C.c_size_t, C.c_int
 PM, PP, PB = C.POINTER(Model), C.POINTER(Params), C.POINTER(Box)
 
@@ -108,6 +134,11 @@ PROTOTYPES = {
     "mvk_space_valid_segment_count": (ip, [PP, ip, vp, vp]),
     "mvk_space_max_extent": (d, [PP, ip]),
     "mvk_space_unpack": (ip, [PP, ip, vp, vp]),
+    "mvk_plan_rrt_connect_cb": (ip, [PP, ip, C.POINTER(Checker), C.POINTER(PlanRequest), vp, ip, C.POINTER(PlanResult)]),
+    "mvk_plan_rrt_connect": (ip, [vp, C.POINTER(PlanRequest), vp, ip, C.POINTER(PlanResult)]),
+    "mvk_path_densify": (ip, [PP, ip, vp, ip, vp, ip]),
+    "mvk_path_log_save": (ip, [C.c_char_p, C.POINTER(PathLog), vp]),
+    "mvk_path_log_load": (ip, [C.c_char_p, ip, C.POINTER(PathLog), vp, ip]),
 }
 
 _LIB = None

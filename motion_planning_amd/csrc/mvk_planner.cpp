@@ -1,0 +1,356 @@
+// mvk_planner.cpp -- host-side RRT-Connect over the batched validity checker,
+// solution densification and the reference's path-log text format.
+//
+// Reference anchors (paths relative to the reference root):
+//   plan / densify   aerial_motion/sampling_based_method/src/motion_planning.cpp:377-463
+//   savePath         :644-688        loadPath  :690-800
+// The reference instantiates OMPL's RRT* (:396-400); RRT-Connect is this build's own
+// planner following the structure of OMPL's RRTConnect:
+// two trees rooted at start and goal, EXTEND toward a uniform sample by at most
+// `range`, then CONNECT the other tree greedily toward the new node, swap.
+// What is MI355X-shaped about it: validity is never asked one state at a time.
+// Each iteration proposes `batch` extensions and sends them to ONE edge-check
+// launch; the connect step is ONE more launch whose first_invalid output says how
+// far each straight connection got (the greedy repeat-extend of RRT-Connect
+// collapses into "advance to the last valid interpolation step").
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "mvk_internal.h"
+
+namespace mvk {
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// splitmix64 / xoshiro256** : small, seedable, reproducible across platforms
+struct Rng {
+  uint64_t s[4];
+  explicit Rng(uint64_t seed) {
+    for (auto& v : s) {
+      seed += 0x9E3779B97F4A7C15ull;
+      uint64_t z = seed;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      v = z ^ (z >> 31);
+    }
+  }
+  static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+  uint64_t next() {
+    const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+    return r;
+  }
+  double uniform() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); }
+  double uniform(double lo, double hi) { return lo + (hi - lo) * uniform(); }
+  double normal() {  // Box-Muller
+    const double u1 = 1.0 - uniform(), u2 = uniform();
+    return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * kPi * u2);
+  }
+};
+
+struct Tree {
+  int dim;
+  std::vector<double> states;  // row-major [n][dim]
+  std::vector<int> parent;
+  int size() const { return static_cast<int>(parent.size()); }
+  const double* at(int i) const { return states.data() + static_cast<size_t>(i) * dim; }
+  int add(const double* s, int par) {
+    states.insert(states.end(), s, s + dim);
+    parent.push_back(par);
+    return size() - 1;
+  }
+};
+
+// uniform sample of the planner's space (OMPL's default samplers: box-uniform
+// RealVector, uniform SO2 angle, uniform SO3 quaternion)
+void sample_uniform(const mvk_params& p, int J, Rng& rng, double* s) {
+  int off = 0;
+  if (p.planning_mode != MVK_MODE_ONLY_JOINTS) {
+    if (p.motion_type == MVK_SE2) {
+      s[0] = rng.uniform(p.pos_low[0], p.pos_high[0]);
+      s[1] = rng.uniform(p.pos_low[1], p.pos_high[1]);
+      s[2] = rng.uniform(-kPi, kPi);
+      off = 3;
+    } else {
+      for (int k = 0; k < 3; ++k) s[k] = rng.uniform(p.pos_low[k], p.pos_high[k]);
+      double q[4], n = 0.0;
+      for (double& v : q) { v = rng.normal(); n += v * v; }
+      n = 1.0 / std::sqrt(n);
+      for (int k = 0; k < 4; ++k) s[3 + k] = q[k] * n;
+      off = 7;
+    }
+  }
+  if (p.planning_mode != MVK_MODE_ONLY_BASE)
+    for (int j = 0; j < J; ++j) s[off + j] = rng.uniform(p.joint_low[j], p.joint_high[j]);
+}
+
+int nearest(const mvk_params& p, int J, const Tree& t, const double* s, double* dist_out) {
+  int best = 0;
+  double bd = INFINITY;
+  for (int i = 0; i < t.size(); ++i) {
+    const double d = mvk_space_distance(&p, J, t.at(i), s);
+    if (d < bd) { bd = d; best = i; }
+  }
+  *dist_out = bd;
+  return best;
+}
+
+struct EdgeBatch {  // SoA staging for one check_motions call
+  int dim;
+  std::vector<double> a, b;
+  std::vector<int32_t> nd, first;
+  std::vector<uint8_t> ok;
+  void pack(const std::vector<const double*>& from, const std::vector<std::vector<double>>& to, const mvk_params& p, int J) {
+    const size_t n = from.size();
+    a.assign(n * dim, 0.0);
+    b.assign(n * dim, 0.0);
+    nd.resize(n);
+    first.assign(n, 0);
+    ok.assign(n, 0);
+    for (size_t e = 0; e < n; ++e) {
+      for (int r = 0; r < dim; ++r) {
+        a[static_cast<size_t>(r) * n + e] = from[e][r];
+        b[static_cast<size_t>(r) * n + e] = to[e][r];
+      }
+      int c = mvk_space_valid_segment_count(&p, J, from[e], to[e].data());
+      nd[e] = c < 1 ? 1 : c;
+    }
+  }
+};
+
+}  // namespace
+}  // namespace mvk
+
+using namespace mvk;
+
+extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mvk_checker* ck,
+                                       const mvk_plan_request* req, double* waypoints, int cap,
+                                       mvk_plan_result* out) {
+  if (!params || !ck || !ck->check_states || !ck->check_motions || !req || !req->start || !req->goal || !out)
+    return fail(MVK_ERR_INVALID_ARG, "mvk_plan_rrt_connect: null argument");
+  const mvk_params& p = *params;
+  const int dim = space_dim(&p, J);
+  std::memset(out, 0, sizeof(*out));
+  const auto t0 = std::chrono::steady_clock::now();
+  auto elapsed_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+
+  // start / goal validity (planInit aborts on a colliding start: motion_planning.cpp:364-372)
+  {
+    std::vector<double> soa(2 * dim);
+    for (int r = 0; r < dim; ++r) { soa[2 * r] = req->start[r]; soa[2 * r + 1] = req->goal[r]; }
+    uint8_t ok[2] = {0, 0};
+    if (int rc = ck->check_states(ck->user, soa.data(), 2, 2, ok)) return rc;
+    out->state_checks += 2;
+    if (!ok[0] || !ok[1]) {
+      out->solve_ms = elapsed_ms();
+      return fail(MVK_ERR_NO_SOLUTION, "%s state is invalid, stop planning", !ok[0] ? "start" : "goal");
+    }
+  }
+  const double range = req->range > 0.0 ? req->range : 0.2 * mvk_space_max_extent(&p, J);
+  const int batch = req->batch < 1 ? 1 : req->batch;
+  Rng rng(req->seed);
+  Tree tree[2] = {Tree{dim, {}, {}}, Tree{dim, {}, {}}};
+  tree[0].add(req->start, -1);
+  tree[1].add(req->goal, -1);
+  EdgeBatch eb;
+  eb.dim = dim;
+  int link[2] = {-1, -1};  // indices of the two nodes that meet (same state in both trees)
+  bool solved = false;
+  int cur = 0;
+  std::vector<double> sample(dim);
+
+  while (!solved) {
+    if (req->max_iterations > 0 && out->iterations >= static_cast<uint64_t>(req->max_iterations)) break;
+    if (req->time_limit_s > 0.0 && elapsed_ms() > req->time_limit_s * 1e3) break;
+    ++out->iterations;
+    Tree& ta = tree[cur];
+    Tree& tb = tree[1 - cur];
+    // ---- EXTEND: `batch` independent samples, one launch -------------------
+    std::vector<const double*> from;
+    std::vector<std::vector<double>> to;
+    std::vector<int> from_idx;
+    for (int k = 0; k < batch; ++k) {
+      sample_uniform(p, J, rng, sample.data());
+      double d;
+      const int ni = nearest(p, J, ta, sample.data(), &d);
+      std::vector<double> tgt(dim);
+      if (d > range) mvk_space_interpolate(&p, J, ta.at(ni), sample.data(), range / d, tgt.data());
+      else tgt = sample;
+      if (!(d > 0.0)) continue;
+      from_idx.push_back(ni);
+      to.push_back(std::move(tgt));
+    }
+    if (to.empty()) continue;
+    for (int ni : from_idx) from.push_back(ta.at(ni));
+    eb.pack(from, to, p, J);
+    if (int rc = ck->check_motions(ck->user, eb.a.data(), eb.b.data(), to.size(), to.size(), eb.nd.data(), eb.ok.data(), eb.first.data())) return rc;
+    out->edge_checks += to.size();
+    for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
+    std::vector<int> fresh;
+    for (size_t e = 0; e < to.size(); ++e)
+      if (eb.ok[e]) fresh.push_back(ta.add(to[e].data(), from_idx[e]));
+    if (fresh.empty()) { cur = 1 - cur; continue; }
+    // ---- CONNECT: straight shots from the other tree toward every fresh node ----
+    from.clear();
+    std::vector<std::vector<double>> goal_states;
+    std::vector<int> near_idx;
+    for (int fi : fresh) {
+      double d;
+      const int ni = nearest(p, J, tb, ta.at(fi), &d);
+      near_idx.push_back(ni);
+      goal_states.emplace_back(ta.at(fi), ta.at(fi) + dim);
+    }
+    for (int ni : near_idx) from.push_back(tb.at(ni));
+    eb.pack(from, goal_states, p, J);
+    if (int rc = ck->check_motions(ck->user, eb.a.data(), eb.b.data(), fresh.size(), fresh.size(), eb.nd.data(), eb.ok.data(), eb.first.data())) return rc;
+    out->edge_checks += fresh.size();
+    for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
+    for (size_t e = 0; e < fresh.size() && !solved; ++e) {
+      if (eb.ok[e]) {
+        link[cur] = fresh[e];
+        link[1 - cur] = tb.add(ta.at(fresh[e]), near_idx[e]);
+        solved = true;
+      } else if (eb.first[e] > 1) {
+        // trapped part-way: keep the last valid interpolation step as a new node
+        std::vector<double> adv(dim);
+        const double t = static_cast<double>(eb.first[e] - 1) / static_cast<double>(eb.nd[e]);
+        const std::vector<double> nb(tb.at(near_idx[e]), tb.at(near_idx[e]) + dim);
+        mvk_space_interpolate(&p, J, nb.data(), ta.at(fresh[e]), t, adv.data());
+        tb.add(adv.data(), near_idx[e]);
+      }
+    }
+    cur = 1 - cur;
+  }
+  out->solve_ms = elapsed_ms();
+  out->tree_sizes[0] = tree[0].size();
+  out->tree_sizes[1] = tree[1].size();
+  if (!solved) return fail(MVK_ERR_NO_SOLUTION, "No solution found");
+  // start -> meeting node (reverse of the parent walk), then meeting node -> goal
+  std::vector<int> head;
+  for (int i = link[0]; i >= 0; i = tree[0].parent[i]) head.push_back(i);
+  std::vector<const double*> path;
+  for (auto it = head.rbegin(); it != head.rend(); ++it) path.push_back(tree[0].at(*it));
+  for (int i = tree[1].parent[link[1]]; i >= 0; i = tree[1].parent[i]) path.push_back(tree[1].at(i));
+  out->solved = 1;
+  out->n_waypoints = static_cast<int>(path.size());
+  for (size_t i = 1; i < path.size(); ++i) out->path_length += mvk_space_distance(&p, J, path[i - 1], path[i]);
+  if (!waypoints || cap < out->n_waypoints) return fail(MVK_ERR_CAPACITY, "way-point buffer too small (%d needed)", out->n_waypoints);
+  for (size_t i = 0; i < path.size(); ++i) std::memcpy(waypoints + i * dim, path[i], sizeof(double) * dim);
+  return MVK_OK;
+}
+
+namespace {
+int gpu_check_states(void* user, const double* soa, size_t n, size_t ld, uint8_t* ok) {
+  return mvk_is_valid_batch(static_cast<mvk_ctx*>(user), soa, n, ld, MVK_LAYOUT_OMPL, ok, nullptr, nullptr, nullptr);
+}
+int gpu_check_motions(void* user, const double* s1, const double* s2, size_t n, size_t ld, const int32_t* nd,
+                      uint8_t* ok, int32_t* first) {
+  return mvk_check_motion_batch(static_cast<mvk_ctx*>(user), s1, s2, n, ld, nd, 0, ok, first);
+}
+}  // namespace
+
+extern "C" int mvk_plan_rrt_connect(mvk_ctx* ctx, const mvk_plan_request* req, double* waypoints, int cap,
+                                    mvk_plan_result* out) {
+  if (!ctx) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  mvk_params p;
+  if (int rc = mvk_get_params(ctx, &p)) return rc;
+  const int J = mvk_state_dim(ctx, MVK_LAYOUT_POSE7) - 7;
+  mvk_checker ck{gpu_check_states, gpu_check_motions, ctx};
+  return mvk_plan_rrt_connect_cb(&p, J, &ck, req, waypoints, cap, out);
+}
+
+// motion_planning.cpp:424-446
+extern "C" int mvk_path_densify(const mvk_params* p, int J, const double* wp, int n, double* states, int cap) {
+  if (!p || !wp || n < 1) return fail(MVK_ERR_INVALID_ARG, "mvk_path_densify: bad argument");
+  const int dim = space_dim(p, J);
+  int count = 0;
+  auto emit = [&](const double* s) {
+    if (states && count < cap) std::memcpy(states + static_cast<size_t>(count) * dim, s, sizeof(double) * dim);
+    ++count;
+  };
+  std::vector<double> tmp(dim);
+  for (int i = 1; i < n; ++i) {
+    const double* s1 = wp + static_cast<size_t>(i - 1) * dim;
+    const double* s2 = wp + static_cast<size_t>(i) * dim;
+    emit(s1);                                                     // addState(state1)   :433
+    const int nd = mvk_space_valid_segment_count(p, J, s1, s2);   // :434
+    for (int j = 1; j < nd; ++j) {                                // :438-443
+      mvk_space_interpolate(p, J, s1, s2, static_cast<double>(j) / static_cast<double>(nd), tmp.data());
+      emit(tmp.data());
+    }
+    emit(s2);                                                     // addState(state2)   :445
+  }
+  if (states && count > cap) return fail(MVK_ERR_CAPACITY, "densified path needs %d states", count);
+  return count;
+}
+
+// savePath (motion_planning.cpp:644-688).  Layout of the reference's committed logs
+// (path_log/hydrus/hydrus_planning_log.txt); the J stray newlines of quirk Q6 are not emitted,
+// so the file round-trips through loadPath.
+extern "C" int mvk_path_log_save(const char* file, const mvk_path_log* h, const double* states) {
+  if (!file || !h || (h->n_states > 0 && !states)) return fail(MVK_ERR_INVALID_ARG, "mvk_path_log_save: null argument");
+  std::ofstream ofs(file);
+  if (!ofs) return fail(MVK_ERR_IO, "cannot open %s for writing", file);
+  const int w = 7 + h->n_joint;
+  auto row = [&](const double* s) {
+    for (int i = 0; i < w; ++i) ofs << " " << s[i];
+    ofs << std::endl;
+  };
+  ofs << "start_state_: "; row(h->start);
+  ofs << "goal_state_: "; row(h->goal);
+  ofs << "states: " << h->n_states << std::endl;
+  ofs << "planning_mode: " << h->planning_mode << std::endl;
+  ofs << "planning_time: " << h->planning_time << std::endl;
+  ofs << "motion_cost: " << h->motion_cost << std::endl;
+  ofs << "minimum_var: " << h->minimum_var << std::endl;
+  ofs << "minimum_var_state_entry: " << h->minimum_var_state_entry << std::endl;
+  for (int k = 0; k < h->n_states; ++k) {
+    ofs << "state" << k << ": ";
+    row(states + static_cast<size_t>(k) * w);
+  }
+  ofs << "end" << std::endl;
+  return ofs ? MVK_OK : fail(MVK_ERR_IO, "write to %s failed", file);
+}
+
+// loadPath (motion_planning.cpp:690-800).  Quirk Q7 (goal parsed from the exhausted start
+// stream) is NOT reproduced: the goal line is parsed from its own line.
+extern "C" int mvk_path_log_load(const char* file, int J, mvk_path_log* h, double* states, int cap) {
+  if (!file || !h || J < 0 || J > MVK_MAX_JOINT) return fail(MVK_ERR_INVALID_ARG, "mvk_path_log_load: bad argument");
+  std::ifstream ifs(file);
+  if (!ifs) return fail(MVK_ERR_IO, "File do not exist: %s", file);
+  std::memset(h, 0, sizeof(*h));
+  h->n_joint = J;
+  const int w = 7 + J;
+  std::string line, header;
+  auto read_row = [&](double* dst) -> bool {
+    if (!std::getline(ifs, line)) return false;
+    std::stringstream ss(line);
+    ss >> header;
+    for (int i = 0; i < w; ++i)
+      if (!(ss >> dst[i])) return false;
+    return true;
+  };
+  if (!read_row(h->start) || !read_row(h->goal)) return fail(MVK_ERR_IO, "%s: malformed start/goal line", file);
+  auto read_kv = [&](auto& dst) -> bool {
+    if (!std::getline(ifs, line)) return false;
+    std::stringstream ss(line);
+    ss >> header >> dst;
+    return !ss.fail();
+  };
+  if (!read_kv(h->n_states) || !read_kv(h->planning_mode) || !read_kv(h->planning_time) || !read_kv(h->motion_cost) ||
+      !read_kv(h->minimum_var) || !read_kv(h->minimum_var_state_entry))
+    return fail(MVK_ERR_IO, "%s: malformed header", file);
+  std::vector<double> tmp(w);
+  for (int k = 0; k < h->n_states; ++k) {
+    if (!read_row(tmp.data())) return fail(MVK_ERR_IO, "%s: malformed state line %d", file, k);
+    if (states && k < cap) std::memcpy(states + static_cast<size_t>(k) * w, tmp.data(), sizeof(double) * w);
+  }
+  return h->n_states;
+}

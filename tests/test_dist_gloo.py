@@ -1,0 +1,92 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch, all-gather the packed masks and reduce the statistics.
+Per-rank flags come from the CPU oracle here (the GPU kernel is exercised by the -m gpu tests); what is under
+test is the sharding / gather / reduce logic that bench.py and multi-GPU callers use."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as tmp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import common
+    import oracle_lib as O
+    from motion_planning_amd import dist as D
+    w = common.config2(n=n)
+    lo, hi = D.shard_range(n, rank, world)
+    r = O.eval_batch(w.model, w.boxes, w.params, w.soa[:, lo:hi], w.layout)
+    flags = r["flags"]
+    words = (hi - lo + 63) // 64
+    padded = np.zeros(words * 64, np.uint8)
+    padded[: hi - lo] = flags
+    local_mask = torch.from_numpy(np.packbits(padded, bitorder="little").view(np.int64).copy())
+    full = D.gather_masks(local_mask, n)
+    fin = np.isfinite(r["min_dist"])
+    local = dict(n=hi - lo, valid_count=int(flags.sum()), band_count=int(r["band"].sum()),
+                 min_dist=float(r["min_dist"].min()), min_dist_index=int(r["min_dist"].argmin()),
+                 min_margin=float(r["margin"].min()), min_margin_index=int(r["margin"].argmin()),
+                 min_thrust=float(np.nanmin(r["thrust"])), min_thrust_index=int(np.nanargmin(np.nanmin(r["thrust"], 0))),
+                 max_thrust=float(np.nanmax(r["thrust"])), max_thrust_index=int(np.nanargmax(np.nanmax(r["thrust"], 0))),
+                 min_rp_position_margin=float(r["rp_position_margin"].min()),
+                 min_rp_position_margin_index=int(r["rp_position_margin"].argmin()))
+    st = D.reduce_stats(local, lo, torch.device("cpu"))
+    q.put((rank, lo, hi, full.numpy().copy(), st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_gather_reduce():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import common
+    import oracle_lib as O
+    n, world = 1000, 2      # ragged: not a multiple of 64 * world
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = common.config2(n=n)
+    ref = O.eval_batch(w.model, w.boxes, w.params, w.soa, w.layout)
+    ranges = sorted((lo, hi) for _, lo, hi, _, _ in got)
+    assert ranges[0][0] == 0 and ranges[-1][1] == n and ranges[0][1] == ranges[1][0] and ranges[0][1] % 64 == 0
+    for rank, lo, hi, full, st in got:
+        bits = np.unpackbits(full.view(np.uint8), bitorder="little")[:n]
+        assert np.array_equal(bits, ref["flags"])           # every rank holds the whole mask
+        assert st["n"] == n and st["valid_count"] == int(ref["flags"].sum())
+        assert st["min_dist"] == ref["min_dist"].min() and st["min_dist_index"] == int(ref["min_dist"].argmin())
+        assert st["min_margin"] == ref["margin"].min() and st["min_margin_index"] == int(ref["margin"].argmin())
+        assert st["max_thrust"] == np.nanmax(ref["thrust"])
+        assert st["min_rp_position_margin_index"] == int(ref["rp_position_margin"].argmin())
+
+
+def test_shard_ranges_cover_and_align():
+    from motion_planning_amd import dist as D
+    for n in (0, 1, 63, 64, 65, 1000, 1 << 20, (1 << 26) + 17):
+        for world in (1, 2, 3, 4, 8):
+            rs = [D.shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            for (a, b), (c, d_) in zip(rs, rs[1:]):
+                assert b == c and (b % 64 == 0 or b == n)

@@ -1,0 +1,54 @@
+"""RRT-Connect on the GPU checker (config c1 scene + a 6-link variant), verified edge by edge with the CPU oracle."""
+import numpy as np
+import pytest
+
+import common
+import motion_planning_amd as mp
+import oracle_lib as O
+from motion_planning_amd import _abi as A
+from motion_planning_amd import planner as PL
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gap_pass_hydrus_quad_gpu_checker():
+    model, params, boxes, start, goal = common.config1()
+    eng = mp.Engine(model, boxes, params)
+    wp, info = PL.plan_rrt_connect(eng, start, goal, time_limit_s=60.0, seed=3, batch=64)
+    assert wp is not None, info
+    print("c1 GPU-checker plan:", info)
+    sp = O.Space(params, 3)
+    nd = np.array([max(1, sp.valid_segment_count(wp[i], wp[i + 1])) for i in range(len(wp) - 1)], np.int32)
+    ok, _, band = O.check_motion_batch(model, boxes, params, wp[:-1].T.copy(), wp[1:].T.copy(), nd)
+    assert np.all(ok | band)
+    # densified path: evaluate on the GPU with details, and compare its running extrema with the oracle
+    dense = PL.densify(params, 3, wp)
+    full = eng.eval_batch(dense.T.copy(), A.LAYOUT_OMPL)
+    st = eng.reduce_stats()
+    ref = O.eval_batch(model, boxes, params, dense.T.copy(), A.LAYOUT_OMPL)
+    inb = (ref["band"] | full["band"]).astype(bool)
+    assert np.all(full["flags"][~inb] == 1)
+    assert st["min_rp_position_margin"] == pytest.approx(ref["rp_position_margin"].min(), rel=1e-9)
+    assert st["min_rp_position_margin_index"] == int(ref["rp_position_margin"].argmin())
+    assert st["max_thrust"] == pytest.approx(np.nanmax(ref["thrust"]), rel=1e-9)
+    eng.close()
+
+
+def test_same_seed_same_plan_on_gpu_and_cpu_checkers():
+    """the search is deterministic given the checker's answers: with flags bit-exact, both checkers give one plan"""
+    model, params, boxes, start, goal = common.config1()
+    goal = np.array([-1.0, 1.2, 0.3, 1.2, 1.57, 1.0])     # an easy query on the start side of the wall
+    eng = mp.Engine(model, boxes, params)
+    a, ia = PL.plan_rrt_connect(eng, start, goal, time_limit_s=30.0, seed=11, batch=8)
+    eng.close()
+
+    def cs(soa):
+        return O.eval_batch(model, boxes, params, soa, A.LAYOUT_OMPL)["flags"]
+
+    def cm(s1, s2, nd):
+        ok, first, _ = O.check_motion_batch(model, boxes, params, s1, s2, nd)
+        return ok, first
+    b, ib = PL.plan_rrt_connect_cb(params, 3, cs, cm, start, goal, time_limit_s=60.0, seed=11, batch=8)
+    assert a is not None and b is not None
+    assert a.shape == b.shape and np.array_equal(a, b)
+    assert ia["iterations"] == ib["iterations"] and ia["edge_checks"] == ib["edge_checks"]
