@@ -52,6 +52,26 @@ def cpu_baseline(w, budget_s=12.0):
             "sample": f"first {n2} samples of the {w.name} batch, flag-only predicate, {cores} threads"}
 
 
+def rrt_connect_gap_pass(repeats=5):
+    """Second half of BASELINE.json's metric: RRT-Connect gap-pass solve time (config c1: HYDRUS quad through
+    the default horizontal gap world) on the GPU checker.  Median over seeds of the search wall time."""
+    import common
+    import motion_planning_amd as mp
+    from motion_planning_amd import planner as PL
+    model, params, boxes, start, goal = common.config1()
+    eng = mp.Engine(model, boxes, params)
+    runs = []
+    for seed in range(1, repeats + 1):
+        wp, info = PL.plan_rrt_connect(eng, start, goal, time_limit_s=20.0, seed=seed, batch=64)
+        runs.append(dict(seed=seed, solved=int(info["solved"]), solve_ms=info["solve_ms"], iterations=int(info["iterations"]),
+                         edge_checks=int(info["edge_checks"]), state_checks_in_edges=int(info["edge_steps"]),
+                         waypoints=int(info["n_waypoints"])))
+    eng.close()
+    ok = [r["solve_ms"] for r in runs if r["solved"]]
+    return {"config": "c1: HYDRUS quad, joints+base SE2, horizontal gap world (4 boxes), batch 64", "unit": "ms",
+            "median_solve_ms": float(np.median(ok)) if ok else None, "solved": len(ok), "runs": runs}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +80,7 @@ def main():
     ap.add_argument("--samples", type=int, default=1 << 20)
     ap.add_argument("--workload", default="c2", choices=["c2", "c2se3", "c3", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-planner", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -168,6 +189,8 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
+        if not args.no_planner and world == 1:
+            out["rrt_connect"] = rrt_connect_gap_pass()
         print(json.dumps(out))
     eng.close()
     if world > 1:

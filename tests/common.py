@@ -90,6 +90,10 @@ def config5(n=1 << 20, n_boxes=1000):
     model = mp.make_model("hydrus", 8)
     params = mp.default_params(model, A.MODE_JOINTS_AND_BASE, A.SE3)
     boxes = random_boxes(rng_for(3), n_boxes, [-3.0] * 3, [3.0] * 3, 0.02, 0.25, "so3")
+    # the robot sweeps the z = 0 plane about the origin: keep a clear disc of 1.3 m there so that compact
+    # configurations are collision free and extended ones are not (otherwise every sample collides)
+    slab = (np.abs(boxes[:, 2]) < 0.75) & (np.hypot(boxes[:, 0], boxes[:, 1]) < 1.3)
+    boxes = boxes[~slab]
     J = model.n_joint
     st = np.zeros((7 + J, n))
     st[6] = 1.0

@@ -81,3 +81,28 @@ def test_gap_worlds_literal_numbers():
     assert np.allclose(v[6], [1.0, 0, 0.35, 0, 0, 0, 1, 0.05, 2.0, 0.7])
     assert np.allclose(v[9], [0, -1.0, 0.35, 0, 0, 0, 1, 2.0, 0.05, 0.7])
     assert mp.vertical_gap_scene(0.5, 0.5, 0.7, False).shape == (4, 10)
+
+
+def test_headers_compile_as_c_and_cpp(tmp_path):
+    """include/mvk.h is valid C11; the OMPL-shaped adapter compiles against the OMPL look-alike stub."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "mvk.h")])
+    src = tmp_path / "adapter_use.cpp"
+    src.write_text('''
+#define MVK_OMPL_STUB
+#include "mvk_ompl_adapter.hpp"
+int use(mvk_ctx* ctx) {
+  mvk::StateValidityChecker svc(ctx, 3);
+  mvk::MotionValidator mv(ctx, 3);
+  ompl::base::SE2StateSpace::StateType b1, b2; double j1[3] = {0, 0, 0}, j2[3] = {1, 1, 1};
+  ompl::base::RealVectorStateSpace::StateType r1, r2; r1.values = j1; r2.values = j2;
+  ompl::base::State* c1[2] = {&b1, &r1}; ompl::base::State* c2[2] = {&b2, &r2};
+  ompl::base::CompoundState s1, s2; s1.components = c1; s2.components = c2;
+  std::pair<ompl::base::State*, double> last(&s1, 0.0);
+  const ompl::base::State* many[2] = {&s1, &s2}; std::uint8_t out[2];
+  svc.isValid(many, 2, out);
+  return svc.isValid(&s1) + mv.checkMotion(&s1, &s2) + mv.checkMotion(&s1, &s2, last);
+}
+''')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
