@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=1 << 20)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2se3", "c3", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2se3", "c2k", "c3", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
     args = ap.parse_args()
@@ -106,6 +106,8 @@ def main():
         w = common.config2(n=n)
     elif args.workload == "c2se3":
         w = common.config2(n=n, orient="so3")
+    elif args.workload == "c2k":
+        w = common.config2k(n=n)
     elif args.workload == "c3":
         w = common.config3(n=n)
     else:

@@ -66,6 +66,17 @@ def config2(n=1 << 20, orient="yaw", n_links=6, n_boxes=100):
     return Workload("c2", model, params, boxes, soa, A.LAYOUT_POSE7)
 
 
+def config2k(n=1 << 20, n_boxes=1000):
+    """north-star target workload: HYDRUS 6-link, joints+base SE(2), 1k obstacles.  The c2 volume with 1000 boxes of
+    half extent 0.02-0.25 m (the c3 size law), yawed; boxes fill ~15 % of the volume."""
+    rng = rng_for(6)
+    model = mp.make_model("hydrus", 6)
+    params = mp.default_params(model, A.MODE_JOINTS_AND_BASE, A.SE2)
+    boxes = random_boxes(rng, n_boxes, [-2.0, -2.2, -2.2], [5.0, 2.2, 2.2], 0.02, 0.25, "yaw")
+    soa = hydrus_states(rng, n, model.n_joint, "yaw")
+    return Workload("c2k", model, params, boxes, soa, A.LAYOUT_POSE7)
+
+
 def config3(n=1 << 20, n_boxes=1000):
     """c3: DRAGON 4-link (gimbals), SE(3), 1k randomly oriented boxes in [-3,3]^3."""
     rng = rng_for(3)
