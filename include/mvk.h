@@ -209,6 +209,16 @@ int mvk_scene_vertical_gap(double gap_x_width, double gap_y_width, double gap_he
                            int planning_walls, double ceiling_offset, double side_wall_width,
                            mvk_box* out, int cap);
 
+/* Broadphase diagnostic (host only, no device needed).  mvk_create / mvk_set_scene
+ * index the world boxes in a uniform grid -- the role of FCL's broadphase manager
+ * under PlanningScene::checkCollision (call site motion_planning.cpp:156-161) -- whose
+ * cells list every box within `radius` of any of their points.  This entry point
+ * builds that same grid and returns, for each query point, the ids its cell lists
+ * (a superset of the boxes within `radius` of the point; tests check exactly that).
+ * counts[i] = number of ids for point i (may exceed cap; only cap are written). */
+int mvk_broadphase_query(const mvk_box* boxes, size_t n_boxes, double radius, const double* points /*[n][3]*/,
+                         size_t n_points, int32_t* counts, int32_t* ids /*[n][cap]*/, int cap);
+
 /* ---- context --------------------------------------------------------------- */
 /* Replaces MotionPlanning's ownership of robot_model_ptr_ + planning_scene_
  * (motion_planning.h:128,133; planInit motion_planning.cpp:354-361). */

@@ -113,6 +113,7 @@ PROTOTYPES = {
     "mvk_params_default": (ip, [PM, ip, ip, PP]),
     "mvk_scene_horizontal_gap": (ip, [d, d, d, d, PB, ip]),
     "mvk_scene_vertical_gap": (ip, [d, d, d, ip, d, d, PB, ip]),
+    "mvk_broadphase_query": (ip, [PB, sz, d, vp, sz, vp, vp, ip]),
     "mvk_create": (vp, [PM, PB, sz, PP, ip]),
     "mvk_destroy": (None, [vp]),
     "mvk_set_scene": (ip, [vp, PB, sz]),

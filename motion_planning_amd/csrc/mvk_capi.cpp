@@ -77,7 +77,8 @@ struct mvk_ctx {
   DevExtras extras{};
   mvk_model* d_model = nullptr;
   DevExtras* d_extras = nullptr;
-  Buf obs, obsf;
+  Buf obs, obsf, grid_start, grid_items;
+  GridDev grid{};
   int n_obs = 0;
   float f32_delta = 0.0f;
   double f32_range = 0.0;
@@ -180,10 +181,10 @@ void derive_extras(const mvk_model* m, DevExtras* x) {
   }
 }
 
-int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
-  if (n > 65535) return fail(MVK_ERR_CAPACITY, "at most 65535 obstacles (16-bit candidate ids)");
+int boxes_to_obs(const mvk_box* boxes, size_t n, std::vector<DevObs>& host) {
+  if (n >= static_cast<size_t>(kGridNone)) return fail(MVK_ERR_CAPACITY, "at most %d obstacles (16-bit candidate ids)", kGridNone - 1);
   if (n && !boxes) return fail(MVK_ERR_INVALID_ARG, "null obstacle array");
-  std::vector<DevObs> host(n);
+  host.resize(n);
   for (size_t i = 0; i < n; ++i) {
     DevObs& o = host[i];
     for (int k = 0; k < 3; ++k) {
@@ -196,10 +197,16 @@ int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
       if (!std::isfinite(o.R[k])) return fail(MVK_ERR_INVALID_ARG, "obstacle %zu: invalid quaternion", i);
     o.bound = std::sqrt(o.h[0] * o.h[0] + o.h[1] * o.h[1] + o.h[2] * o.h[2]);
   }
+  return MVK_OK;
+}
+
+int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
+  std::vector<DevObs> host;
+  if (int rc = boxes_to_obs(boxes, n, host)) return rc;
   // fp32 copy for the level-1 cull, and the coordinate range / error bound it is trusted for:
   // every fp32 rounding in the centre-distance evaluation is <= 2^-24 relative to a coordinate
   // difference of at most 2*range; the accumulated bound on the distance error is < 4e-6 * range.
-  std::vector<DevObsF> hostf(n);
+  std::vector<DevObsF> hostf(n + 1);
   double range = 64.0;
   for (size_t i = 0; i < n; ++i) {
     for (int k = 0; k < 3; ++k) {
@@ -211,10 +218,29 @@ int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
     hostf[i].pad = 0.0f;
   }
   if (!(range < 1e6)) return fail(MVK_ERR_INVALID_ARG, "obstacle coordinates beyond 1e6 m");
+  // entry n: the box the grid's padding id resolves to (far away, never a candidate)
+  std::memset(&hostf[n], 0, sizeof(DevObsF));
+  hostf[n].c[0] = hostf[n].c[1] = hostf[n].c[2] = 3.0e18f;
+  hostf[n].R[0] = hostf[n].R[4] = hostf[n].R[8] = 1.0f;
+  // broadphase grid for the largest segment sphere (level-1 cull of the flag path)
+  double rq = 0.0;
+  for (int k = 0; k < c->model.n_seg; ++k) rq = std::fmax(rq, c->extras.seg_sph[k][3]);
+  GridHost gh;
+  if (int rc = build_grid(host.data(), n, rq, gh)) return rc;
   if (int rc = c->obs.reserve(sizeof(DevObs) * (n ? n : 1))) return rc;
-  if (int rc = c->obsf.reserve(sizeof(DevObsF) * (n ? n : 1))) return rc;
+  if (int rc = c->obsf.reserve(sizeof(DevObsF) * (n + 1))) return rc;
+  if (int rc = c->grid_start.reserve(sizeof(uint32_t) * gh.start.size())) return rc;
+  if (int rc = c->grid_items.reserve(sizeof(uint16_t) * (gh.items.size() + kGridGroup))) return rc;
   if (n) HIP_TRY(hipMemcpy(c->obs.p, host.data(), sizeof(DevObs) * n, hipMemcpyHostToDevice));
-  if (n) HIP_TRY(hipMemcpy(c->obsf.p, hostf.data(), sizeof(DevObsF) * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->obsf.p, hostf.data(), sizeof(DevObsF) * (n + 1), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->grid_start.p, gh.start.data(), sizeof(uint32_t) * gh.start.size(), hipMemcpyHostToDevice));
+  if (!gh.items.empty())
+    HIP_TRY(hipMemcpy(c->grid_items.p, gh.items.data(), sizeof(uint16_t) * gh.items.size(), hipMemcpyHostToDevice));
+  for (int k = 0; k < 3; ++k) { c->grid.origin[k] = gh.origin[k]; c->grid.n[k] = gh.n[k]; }
+  c->grid.inv_h = 1.0 / gh.h;
+  c->grid.pad = 0;
+  c->grid.start = static_cast<const uint32_t*>(c->grid_start.p);
+  c->grid.items = static_cast<const uint16_t*>(c->grid_items.p);
   c->n_obs = static_cast<int>(n);
   c->f32_range = range;
   c->f32_delta = static_cast<float>(4e-6 * range);
@@ -250,6 +276,7 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
   a.extras = c->d_extras;
   a.obs = static_cast<const DevObs*>(c->obs.p);
   a.obsf = static_cast<const DevObsF*>(c->obsf.p);
+  a.grid = c->grid;
   a.f32_delta = c->f32_delta;
   a.f32_range = c->f32_range;
   a.n_obs = c->n_obs;
@@ -325,6 +352,28 @@ extern "C" int mvk_device_count(void) {
   return usable;
 }
 
+extern "C" int mvk_broadphase_query(const mvk_box* boxes, size_t n_boxes, double radius, const double* points,
+                                    size_t n_points, int32_t* counts, int32_t* ids, int cap) {
+  if (!(radius >= 0.0) || (n_points && (!points || !counts)) || cap < 0 || (cap > 0 && !ids))
+    return fail(MVK_ERR_INVALID_ARG, "mvk_broadphase_query: bad argument");
+  std::vector<DevObs> host;
+  if (int rc = boxes_to_obs(boxes, n_boxes, host)) return rc;
+  GridHost g;
+  if (int rc = build_grid(host.data(), n_boxes, radius, g)) return rc;
+  for (size_t i = 0; i < n_points; ++i) {
+    const uint16_t* list = nullptr;
+    const int padded = grid_query(g, points + 3 * i, &list);
+    int k = 0;
+    for (int e = 0; e < padded; ++e)
+      if (list[e] != kGridNone) {
+        if (k < cap) ids[i * static_cast<size_t>(cap) + k] = list[e];
+        ++k;
+      }
+    counts[i] = k;
+  }
+  return MVK_OK;
+}
+
 extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, size_t n_boxes,
                                const mvk_params* params, int device) {
   if (!model || !params) {
@@ -383,7 +432,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
   }
   if (c->d_model) (void)hipFree(c->d_model);
   if (c->d_extras) (void)hipFree(c->d_extras);
-  Buf* all[] = {&c->obs, &c->obsf, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
+  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
                 &c->partial, &c->stats_out};
   for (Buf* b : all) b->release();

@@ -1,0 +1,144 @@
+// mvk_grid.cpp -- host-side construction of the broadphase grid over the world
+// boxes (no device code in this file).
+//
+// The collision role MoveIt/FCL's dynamic AABB tree plays in the reference
+// (PlanningScene::checkCollision, call site motion_planning.cpp:156-161) is a
+// uniform grid here: a tree walk is a per-lane pointer chase, a grid is one
+// index computation and one contiguous list read per query.
+//
+// Query the kernels make: "every box within `radius` of point c" (c = centre of
+// a segment's bounding sphere).  The cell holding c lists every box whose
+// distance to ANY point of the cell is <= radius, so a single cell lookup
+// answers the query conservatively; the exact tests that follow decide.  Points
+// outside the grid volume are farther than `radius` from every box by
+// construction (the volume is the boxes' bound inflated by radius).
+//
+// Layout: CSR.  start[c] .. start[c+1] index GROUPS of kGridGroup ids in
+// items[]; every cell's list is padded to whole groups with kGridNone so that a
+// lane fetches kGridGroup candidates with one aligned 8-byte load.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "mvk_internal.h"
+
+namespace mvk {
+
+namespace {
+
+struct CellRange { int lo[3], hi[3]; };
+
+// lower bound on the distance between the cube (centre cc, half side hh) and the
+// oriented box: the larger of (a) the gap between the cube and the box's world
+// AABB and (b) the gap measured in the box frame, where the cube is replaced by
+// its own bounding box along the box axes.  Both never exceed the true distance.
+double cube_box_lower_bound(const DevObs& o, const double ext[3], const double cc[3], double hh) {
+  double a2 = 0.0, b2 = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    const double ga = std::fabs(cc[k] - o.c[k]) - ext[k] - hh;
+    if (ga > 0.0) a2 += ga * ga;
+  }
+  const double d[3] = {cc[0] - o.c[0], cc[1] - o.c[1], cc[2] - o.c[2]};
+  for (int i = 0; i < 3; ++i) {
+    const double t = o.R[i] * d[0] + o.R[3 + i] * d[1] + o.R[6 + i] * d[2];
+    const double e = hh * (std::fabs(o.R[i]) + std::fabs(o.R[3 + i]) + std::fabs(o.R[6 + i]));
+    const double gb = std::fabs(t) - o.h[i] - e;
+    if (gb > 0.0) b2 += gb * gb;
+  }
+  return std::sqrt(std::max(a2, b2));
+}
+
+}  // namespace
+
+int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g) {
+  g.start.clear();
+  g.items.clear();
+  g.radius = radius;
+  for (int k = 0; k < 3; ++k) { g.origin[k] = 0.0; g.n[k] = 1; }
+  g.h = 1.0;
+  if (n == 0) {
+    g.start.assign(2, 0u);
+    return MVK_OK;
+  }
+  if (n >= kGridNone) return fail(MVK_ERR_CAPACITY, "at most %d obstacles (16-bit candidate ids)", kGridNone - 1);
+  // slack for the rounding of the device's cell-index computation (fp64, |coordinates| < 1e6)
+  const double R = radius * (1.0 + 1e-9) + 1e-7;
+  std::vector<double> ext(3 * n);  // half sizes of each box's world AABB
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      const double e = std::fabs(obs[i].R[3 * k]) * obs[i].h[0] + std::fabs(obs[i].R[3 * k + 1]) * obs[i].h[1] +
+                       std::fabs(obs[i].R[3 * k + 2]) * obs[i].h[2];
+      ext[3 * i + k] = e;
+      lo[k] = std::min(lo[k], obs[i].c[k] - e - R);
+      hi[k] = std::max(hi[k], obs[i].c[k] + e + R);
+    }
+  const double vol = (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]);
+  double h = std::max(0.5 * R, std::cbrt(vol / static_cast<double>(kGridMaxCells)));
+  for (int attempt = 0; attempt < 40; ++attempt, h *= 1.25) {
+    uint64_t ncell = 1;
+    int dim[3];
+    for (int k = 0; k < 3; ++k) {
+      dim[k] = static_cast<int>(std::ceil((hi[k] - lo[k]) / h));
+      if (dim[k] < 1) dim[k] = 1;
+      ncell *= static_cast<uint64_t>(dim[k]);
+    }
+    if (ncell > kGridMaxCells) continue;
+    const double hh = 0.5 * h;
+    auto range_of = [&](size_t i) {
+      CellRange r;
+      for (int k = 0; k < 3; ++k) {
+        r.lo[k] = std::max(0, static_cast<int>(std::floor((obs[i].c[k] - ext[3 * i + k] - R - lo[k]) / h)) - 1);
+        r.hi[k] = std::min(dim[k] - 1, static_cast<int>(std::floor((obs[i].c[k] + ext[3 * i + k] + R - lo[k]) / h)) + 1);
+      }
+      return r;
+    };
+    auto for_cells = [&](size_t i, auto&& fn) {
+      const CellRange r = range_of(i);
+      for (int z = r.lo[2]; z <= r.hi[2]; ++z)
+        for (int y = r.lo[1]; y <= r.hi[1]; ++y)
+          for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
+            const double cc[3] = {lo[0] + (x + 0.5) * h, lo[1] + (y + 0.5) * h, lo[2] + (z + 0.5) * h};
+            if (cube_box_lower_bound(obs[i], &ext[3 * i], cc, hh) <= R)
+              fn((static_cast<uint64_t>(z) * dim[1] + y) * dim[0] + x);
+          }
+    };
+    std::vector<uint32_t> count(ncell, 0u);
+    for (size_t i = 0; i < n; ++i) for_cells(i, [&](uint64_t c) { ++count[c]; });
+    uint64_t groups = 0;
+    for (uint64_t c = 0; c < ncell; ++c) groups += (count[c] + kGridGroup - 1) / kGridGroup;
+    if (groups * kGridGroup > kGridMaxItems) continue;
+    g.start.assign(ncell + 1, 0u);
+    uint32_t at = 0;
+    for (uint64_t c = 0; c < ncell; ++c) {
+      g.start[c] = at;
+      at += (count[c] + kGridGroup - 1) / kGridGroup;
+    }
+    g.start[ncell] = at;
+    g.items.assign(static_cast<size_t>(at) * kGridGroup, static_cast<uint16_t>(kGridNone));
+    std::fill(count.begin(), count.end(), 0u);
+    for (size_t i = 0; i < n; ++i)  // boxes in ascending id order inside every cell
+      for_cells(i, [&](uint64_t c) { g.items[static_cast<size_t>(g.start[c]) * kGridGroup + count[c]++] = static_cast<uint16_t>(i); });
+    for (int k = 0; k < 3; ++k) { g.origin[k] = lo[k]; g.n[k] = dim[k]; }
+    g.h = h;
+    return MVK_OK;
+  }
+  return fail(MVK_ERR_CAPACITY, "broadphase grid does not fit its budget (scene too large or too dense)");
+}
+
+int grid_query(const GridHost& g, const double c[3], const uint16_t** ids) {
+  *ids = nullptr;
+  if (g.items.empty()) return 0;
+  int ix[3];
+  const double inv_h = 1.0 / g.h;
+  for (int k = 0; k < 3; ++k) {
+    const double f = (c[k] - g.origin[k]) * inv_h;
+    if (!(f >= 0.0) || !(f < static_cast<double>(g.n[k]))) return 0;
+    ix[k] = static_cast<int>(f);
+  }
+  const uint64_t cell = (static_cast<uint64_t>(ix[2]) * g.n[1] + ix[1]) * g.n[0] + ix[0];
+  *ids = g.items.data() + static_cast<size_t>(g.start[cell]) * kGridGroup;
+  return static_cast<int>(g.start[cell + 1] - g.start[cell]) * kGridGroup;
+}
+
+}  // namespace mvk

@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include "../../include/mvk.h"
 
@@ -23,8 +24,8 @@ struct DevObs {
   double bound;  // circumscribed-sphere radius
 };
 
-// fp32 copy for the level-1 cull: 16 floats = 64 B = one s_load_dwordx16.
-struct DevObsF {
+// fp32 copy for the level-1 cull: 16 floats = 64 B (four 16-byte loads per lane).
+struct alignas(64) DevObsF {
   float c[3];
   float R[9];
   float h[3];
@@ -42,8 +43,29 @@ struct DevExtras {
   double reach;                    // bound on the distance of any primitive point from the root origin
 };
 
-struct SpaceDev {  // what in-kernel interpolation needs
-  int32_t planning_mode, motion_type;
+// ---- broadphase grid (mvk_grid.cpp) ---------------------------------------
+constexpr int kGridGroup = 4;             // candidate ids fetched per 8-byte load
+constexpr int kGridNone = 0xFFFF;         // padding id
+constexpr uint64_t kGridMaxCells = 1u << 17;
+constexpr uint64_t kGridMaxItems = 1u << 23;
+
+struct GridHost {
+  double origin[3], h, radius;
+  int32_t n[3];
+  std::vector<uint32_t> start;  // [ncell + 1], in groups of kGridGroup ids
+  std::vector<uint16_t> items;  // [start[ncell] * kGridGroup]
+};
+// every box within `radius` of a point is listed in the cell holding the point
+int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g);
+// host lookup (tests / diagnostics): returns the padded candidate count, ids in *ids
+int grid_query(const GridHost& g, const double c[3], const uint16_t** ids);
+
+struct GridDev {
+  double origin[3], inv_h;
+  int32_t n[3];
+  int32_t pad;
+  const uint32_t* start;
+  const uint16_t* items;
 };
 
 struct EvalArgs {
@@ -66,7 +88,8 @@ struct EvalArgs {
   const mvk_model* model;
   const DevExtras* extras;
   const DevObs* obs;
-  const DevObsF* obsf;
+  const DevObsF* obsf;   // n_obs + 1 entries: the last one is the padding id's never-hit box
+  GridDev grid;
   int32_t n_obs;
   float f32_delta;   // bound on the fp32 centre-distance error inside f32_range [m]
   double f32_range;  // coordinate magnitude up to which f32_delta holds

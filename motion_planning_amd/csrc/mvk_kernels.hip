@@ -608,35 +608,58 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
       const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
 
       if (!FULL) {
-        // ===== flag path: two-level cull =====================================
-        // level 1 (fp32, wave-uniform obstacle reads): one bounding sphere per segment
-        // against every box; survivors go to this lane's LDS list.  The fp32 test is
-        // conservative: its radius is inflated by f32_delta, a bound on the fp32
-        // evaluation error for coordinates within f32_range (lanes outside that range
-        // keep every box).  level 2 (fp64, per lane): exact centre test + narrowphase
-        // of each primitive of the segment against the listed boxes only.
+        // ===== flag path: grid lookup + two-level cull ========================
+        // level 0: the broadphase grid (mvk_grid.cpp).  The cell holding the centre of
+        // this segment's bounding sphere lists every box within the largest segment
+        // radius of any point of the cell: one index computation + one contiguous list.
+        // level 1 (fp32): sphere vs listed box; survivors go to this lane's LDS list.
+        // The fp32 test is conservative: its radius is inflated by f32_delta, a bound on
+        // the fp32 evaluation error for coordinates within f32_range (lanes outside that
+        // range keep every listed box).  level 2 (fp64, per lane): exact centre test +
+        // narrowphase of each primitive of the segment against the surviving boxes only.
         if (pb == pe) continue;
         double sc[3];
         xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
         const float sx = static_cast<float>(sc[0]), sy = static_cast<float>(sc[1]), sz = static_cast<float>(sc[2]);
         const float thr = (static_cast<float>(X->seg_sph[k][3]) + A.f32_delta) * 1.000001f;
         const float thr2 = f32_safe ? thr * thr : INFINITY;
+        const GridDev& G = A.grid;
+        const double gx = (sc[0] - G.origin[0]) * G.inv_h, gy = (sc[1] - G.origin[1]) * G.inv_h,
+                     gz = (sc[2] - G.origin[2]) * G.inv_h;
+        const bool inside = live && gx >= 0.0 && gy >= 0.0 && gz >= 0.0 && gx < static_cast<double>(G.n[0]) &&
+                            gy < static_cast<double>(G.n[1]) && gz < static_cast<double>(G.n[2]);
+        unsigned gb = 0, ge = 0;
+        if (inside) {
+          const unsigned cell = (static_cast<unsigned>(static_cast<int>(gz)) * G.n[1] + static_cast<unsigned>(static_cast<int>(gy))) * G.n[0] +
+                                static_cast<unsigned>(static_cast<int>(gx));
+          const uint2 se = *reinterpret_cast<const uint2*>(G.start + cell);  // start[cell], start[cell + 1]
+          gb = se.x; ge = se.y;
+        }
         int cnt = 0;
-#pragma unroll 2
-        for (int ob = 0; ob < A.n_obs; ++ob) {
-          const DevObsF& F = obsf[ob];  // 64 B, one s_load_dwordx16
-          const float dx = sx - F.c[0], dy = sy - F.c[1], dz = sz - F.c[2];
-          const float e0 = fmaxf(fabsf(fmaf(F.R[0], dx, fmaf(F.R[3], dy, F.R[6] * dz))) - F.h[0], 0.0f);
-          const float e1 = fmaxf(fabsf(fmaf(F.R[1], dx, fmaf(F.R[4], dy, F.R[7] * dz))) - F.h[1], 0.0f);
-          const float e2 = fmaxf(fabsf(fmaf(F.R[2], dx, fmaf(F.R[5], dy, F.R[8] * dz))) - F.h[2], 0.0f);
-          const float l2 = fmaf(e0, e0, fmaf(e1, e1, e2 * e2));
-          if (live && l2 <= thr2) {
-            if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
-            ++cnt;
+#pragma unroll 1
+        for (unsigned g = gb; __any(g < ge); ++g) {
+          if (g < ge) {
+            const uint2 w = *reinterpret_cast<const uint2*>(G.items + static_cast<size_t>(g) * kGridGroup);
+            const unsigned ids[kGridGroup] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+            DevObsF F[kGridGroup];
+#pragma unroll
+            for (int j = 0; j < kGridGroup; ++j) F[j] = obsf[ids[j] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[j]];
+#pragma unroll
+            for (int j = 0; j < kGridGroup; ++j) {
+              const float dx = sx - F[j].c[0], dy = sy - F[j].c[1], dz = sz - F[j].c[2];
+              const float e0 = fmaxf(fabsf(fmaf(F[j].R[0], dx, fmaf(F[j].R[3], dy, F[j].R[6] * dz))) - F[j].h[0], 0.0f);
+              const float e1 = fmaxf(fabsf(fmaf(F[j].R[1], dx, fmaf(F[j].R[4], dy, F[j].R[7] * dz))) - F[j].h[1], 0.0f);
+              const float e2 = fmaxf(fabsf(fmaf(F[j].R[2], dx, fmaf(F[j].R[5], dy, F[j].R[8] * dz))) - F[j].h[2], 0.0f);
+              const float l2 = fmaf(e0, e0, fmaf(e1, e1, e2 * e2));
+              if (ids[j] != kGridNone && l2 <= thr2) {
+                if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ids[j]);
+                ++cnt;
+              }
+            }
           }
         }
-        const bool overflow = cnt > kListCap;  // fall back to testing every box for this segment
-        const int ntodo = live ? (overflow ? A.n_obs : cnt) : 0;
+        const bool overflow = cnt > kListCap;  // fall back to this cell's whole list for this segment
+        const int ntodo = live ? (overflow ? static_cast<int>(ge - gb) * kGridGroup : cnt) : 0;
         if (__any(ntodo > 0)) {
 #pragma unroll 1
           for (int qi = pb; qi < pe; ++qi) {
@@ -651,15 +674,17 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
 #pragma unroll 1
             for (int e = 0; __any(e < todo); ++e) {
               if (e < todo) {
-                const int ob = overflow ? e : sm.list[e * kBlock + tid];
-                const DevObs O = obs[ob];
-                double t[3];
-                to_box_frame(O, pc, t);
-                const double e0 = excess_abs(t[0], O.h[0]), e1 = excess_abs(t[1], O.h[1]), e2 = excess_abs(t[2], O.h[2]);
-                const double l2 = fma(e0, e0, fma(e1, e1, e2 * e2));
-                bool hit = l2 <= rin2;  // a ball inside the primitive already touches the box
-                if (!hit && type != MVK_PRIM_SPHERE && l2 <= rb2) hit = narrow(type, pc, PR, d0, d1, d2, O, t) <= 0.0;
-                if (hit) { mind = 0.0; live = false; todo = 0; }
+                const unsigned ob = overflow ? G.items[static_cast<size_t>(gb) * kGridGroup + e] : sm.list[e * kBlock + tid];
+                if (ob != kGridNone) {
+                  const DevObs O = obs[ob];
+                  double t[3];
+                  to_box_frame(O, pc, t);
+                  const double e0 = excess_abs(t[0], O.h[0]), e1 = excess_abs(t[1], O.h[1]), e2 = excess_abs(t[2], O.h[2]);
+                  const double l2 = fma(e0, e0, fma(e1, e1, e2 * e2));
+                  bool hit = l2 <= rin2;  // a ball inside the primitive already touches the box
+                  if (!hit && type != MVK_PRIM_SPHERE && l2 <= rb2) hit = narrow(type, pc, PR, d0, d1, d2, O, t) <= 0.0;
+                  if (hit) { mind = 0.0; live = false; todo = 0; }
+                }
               }
             }
           }

@@ -71,6 +71,18 @@ def vertical_gap_scene(gap_x_width=1.0, gap_y_width=1.0, gap_height=0.3, plannin
     return boxes_to_array(out, n)
 
 
+def broadphase_query(boxes, radius, points, cap=256):
+    """Host diagnostic: ids the broadphase grid lists for each query point ([n, 3])."""
+    lib = A.load()
+    arr, m = boxes_from_array(boxes)
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    counts = np.zeros(len(pts), np.int32)
+    ids = np.full((len(pts), cap), -1, np.int32)
+    _check(lib, lib.mvk_broadphase_query(arr, m, float(radius), pts.ctypes.data_as(C.c_void_p), len(pts),
+                                         counts.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), cap))
+    return counts, ids
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
