@@ -146,6 +146,8 @@ _LIB = None
 
 
 def lib_path():
+    if os.environ.get("MVK_LIB"):   # diagnostic builds (profiles/diag.py); never set by tests or bench.py
+        return os.environ["MVK_LIB"]
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmvk.so")
 
 

@@ -78,6 +78,11 @@ struct mvk_ctx {
   mvk_model* d_model = nullptr;
   DevExtras* d_extras = nullptr;
   Buf obs, obsf, grid_start, grid_items;
+  // flag path work queue (undecided states of the screen stage) and its two alternating counters:
+  // call k appends to counter k%2 and zeroes counter (k+1)%2, so no memset sits between launches.
+  // Calls on one ctx must therefore be ordered with respect to each other (one stream at a time).
+  Buf queue, queue_counts;
+  uint64_t call_index = 0;
   GridDev grid{};
   int n_obs = 0;
   float f32_delta = 0.0f;
@@ -118,6 +123,11 @@ int check_model_shape(const mvk_model* m) {
       const int i = m->prim_rotor[q];
       if (i < 0 || i >= NL || m->rotor_seg[i] != m->prim_seg[q]) return fail(MVK_ERR_INVALID_ARG, "primitive %d: gimbal / segment mismatch", q);
     }
+  }
+  for (int k = 0; k < ns; ++k) {
+    int on_seg = 0;
+    for (int q = 0; q < m->n_prim; ++q) on_seg += m->prim_seg[q] == k;
+    if (on_seg > kSegPrimMax) return fail(MVK_ERR_CAPACITY, "segment %d carries %d collision primitives (max %d)", k, on_seg, kSegPrimMax);
   }
   return MVK_OK;
 }
@@ -283,6 +293,18 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
   a.nd_uniform = 1;
 }
 
+// flag path: size the work queue for n lanes and hand this call its pair of counters
+int prepare_queue(mvk_ctx* c, EvalArgs& a, uint64_t n) {
+  if (n > 0xffffffffULL) return fail(MVK_ERR_CAPACITY, "at most 2^32-1 states (or edge steps) per call");
+  if (int rc = c->queue.reserve(n * sizeof(uint32_t))) return rc;
+  uint32_t* counts = static_cast<uint32_t*>(c->queue_counts.p);
+  a.queue = static_cast<uint32_t*>(c->queue.p);
+  a.queue_count = counts + (c->call_index & 1);
+  a.queue_count_next = counts + ((c->call_index + 1) & 1);
+  ++c->call_index;
+  return MVK_OK;
+}
+
 int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
                  uint64_t* d_mask, double* d_min_dist, double* d_margin, uint8_t* d_band,
                  const mvk_detail_out* det, bool force_full, hipStream_t s) {
@@ -317,6 +339,8 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
     a.stats_partial = c->partial.p;
     c->last_blocks = blocks;
     c->last_n = n;
+  } else if (int rc = prepare_queue(c, a, n)) {
+    return rc;
   }
   const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s);
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
@@ -420,6 +444,11 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
     mvk_destroy(c);
     return nullptr;
   }
+  if (c->queue_counts.reserve(2 * sizeof(uint32_t)) != MVK_OK) {
+    mvk_destroy(c);
+    return nullptr;
+  }
+  if ((e = hipMemset(c->queue_counts.p, 0, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(queue counters)", e);
   return c;
 }
 
@@ -432,7 +461,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
   }
   if (c->d_model) (void)hipFree(c->d_model);
   if (c->d_extras) (void)hipFree(c->d_extras);
-  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
+  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->queue, &c->queue_counts, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
                 &c->partial, &c->stats_out};
   for (Buf* b : all) b->release();
@@ -607,6 +636,7 @@ int run_edges_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_e
   a.layout = MVK_LAYOUT_OMPL;
   a.first_invalid = d_first;
   c->stats_valid = false;
+  if (int rc = prepare_queue(c, a, total)) return rc;
   int e = launch_edge_init(d_first, d_nd, a.nd_uniform, n_edges, s);
   if (e == hipSuccess) e = launch_eval(a, c->model.robot_type, c->model.n_rotor, true, s);
   if (e == hipSuccess && d_ok) e = launch_edge_finish(d_first, d_nd, a.nd_uniform, d_ok, n_edges, s);

@@ -106,6 +106,10 @@ struct EvalArgs {
   double* cog;
   double* gimbal;
   int32_t* first_invalid;  // edge mode: atomicMin target
+  // flag path: states the fp32 screen leaves undecided, for the exact stage (ctx-owned)
+  uint32_t* queue;             // [n]
+  uint32_t* queue_count;       // appended to by this call (zero on entry)
+  uint32_t* queue_count_next;  // zeroed by this call for the next one
   // per-block partial statistics (full mode) or nullptr
   void* stats_partial;
 };
@@ -120,6 +124,7 @@ struct StatsPartial {
 };
 
 constexpr int kBlock = 256;
+constexpr int kSegPrimMax = 3;  // collision primitives riding on one segment (checked by mvk_create)
 
 // launchers implemented in mvk_kernels.hip; return hipError_t as int
 int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream);

@@ -31,6 +31,16 @@ namespace {
 // ------------------------------------------------------------------------
 #define DEV __device__ __forceinline__
 
+// Diagnostic builds only (profiles/diag.py, -DMVK_PROF): event counters, one atomic per wave.
+#ifdef MVK_PROF
+__device__ unsigned long long g_prof[32];
+#define PROF_LANES(idx, pred) do { const unsigned long long b__ = __ballot(pred); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_prof[idx], (unsigned long long)__popcll(b__)); } while (0)
+#define PROF_WAVE(idx) do { if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_prof[idx], 1ull); } while (0)
+#else
+#define PROF_LANES(idx, pred) do { } while (0)
+#define PROF_WAVE(idx) do { } while (0)
+#endif
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
 template <int B, int E, class F>
 DEV void static_for(F&& f) {
@@ -248,13 +258,18 @@ struct Shape {
   static constexpr int rotor_seg(int i) { return kGimbal ? 2 * i : i; }
 };
 
-constexpr int kListCap = 32;  // per-lane narrowphase candidates per primitive
+constexpr int kListCap = 32;     // full path: per-lane narrowphase candidates per primitive
+constexpr int kPairCap = 12;     // flag path: per-lane fp64 candidates per primitive
 
+// LDS views.  The pointers carry the LDS address space explicitly so that every access is a
+// ds_read / ds_write (a generic pointer would go through flat instructions and aperture checks).
+typedef __attribute__((address_space(3))) double lds_double;
+typedef __attribute__((address_space(3))) unsigned short lds_ushort;
 struct Smem {
   // [2*J][kBlock] cos/sin of the planned joints, lane-contiguous
-  double* cs;
-  // [kListCap][kBlock] candidate obstacle ids
-  unsigned short* list;
+  lds_double* cs;
+  // [list length][kBlock] candidate obstacle ids
+  lds_ushort* list;
 };
 
 // gimbal (roll, pitch) that turn the thrust axis onto the CoG z axis
@@ -271,11 +286,16 @@ DEV void gimbal_cs(double zlx, double zly, double zlz, double& cr, double& sr, d
   sp = zlx * n;
 }
 
+// ------------------------------------------------------------------------
+// walk 1: FK, centre of gravity, rotor geometry, statics, stability margin
+// ------------------------------------------------------------------------
+// Replaces MultilinkState::setStatesFromRoot -> RobotModel::updateRobotModel
+// (multilink_state.cpp:98-137) and stabilityCheck() (motion_planning.cpp:150).
+// Leaves cos/sin of the planned joints in LDS slot `tid` for the collision walks.
 template <int ROBOT, int NL, bool FULL>
-DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
-                    const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf,
-                    const double st[7 + Shape<ROBOT, NL>::kJoint],
-                    const Smem& sm, uint64_t gi, StateOut& out, double* thrust_out /*[NL] or nullptr*/) {
+DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                      const double st[7 + Shape<ROBOT, NL>::kJoint], const Smem& sm, uint64_t gi, StateOut& out,
+                      double Rw[9], bool& finite, double* thrust_out /*[NL] or nullptr*/) {
   using S = Shape<ROBOT, NL>;
   constexpr int NS = S::kSeg, NJ = S::kJoint, D = S::kDof;
   const int tid = threadIdx.x;
@@ -284,15 +304,14 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
   out.min_dist = INFINITY; out.margin = INFINITY;
   out.fc_t_min = NAN; out.fc_rp_min = NAN; out.rp_margin = NAN; out.lam_min = NAN; out.lam_max = NAN;
 
-  double Rw[9];
   quat_to_mat(st[3], st[4], st[5], st[6], Rw);
-  bool finite = true;
+  finite = true;
 #pragma unroll
   for (int k = 0; k < 7 + NJ; ++k) finite = finite && isfinite(st[k]);
 #pragma unroll
   for (int k = 0; k < 9; ++k) finite = finite && isfinite(Rw[k]);
 
-  // joint cos/sin -> LDS (read back by the rolled collision walk)
+  // joint cos/sin -> LDS (read back by the rolled collision walks)
   double jc[NJ], js[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -301,7 +320,6 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
     sm.cs[(2 * j + 1) * kBlock + tid] = js[j];
   }
 
-  // ---- walk 1: FK, centre of gravity, rotor geometry ----------------------
   double R[9], p[3];
 #pragma unroll
   for (int k = 0; k < 9; ++k) R[k] = Rw[k];
@@ -311,7 +329,7 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
   double E[S::kGimbal ? 2 * NL : 1][3];
   static_for<0, NS>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    if (k > 0) {
+    if constexpr (k > 0) {
       double pn[3];
       xform(R, p, M->seg_t[k][0], M->seg_t[k][1], M->seg_t[k][2], pn);
       p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
@@ -511,252 +529,396 @@ DEV void eval_state(const EvalArgs& A, const mvk_model* __restrict__ M, const De
   if (singular) margin = -INFINITY;
   out.margin = margin;
   out.stable = margin >= 0.0;
+}
 
-  // ---- walk 2: collision primitives vs world boxes --------------------------
-  // lanes that cannot change their verdict any more stop generating work
-  bool live = finite && A.do_coll && (FULL || !A.do_stab || out.stable);
-  double mind = INFINITY;  // running exact minimum (FULL) / <= 0 once a hit is found
-  // the fp32 segment cull is only trusted while every coordinate stays inside f32_range
-  const bool f32_safe = fmax(fabs(st[0]), fmax(fabs(st[1]), fabs(st[2]))) + X->reach <= A.f32_range;
-  if (A.do_coll && A.n_obs > 0 && __any(live)) {
+// ------------------------------------------------------------------------
+// walk 2 building blocks: the chain frame, primitive poses, box-frame tests
+// ------------------------------------------------------------------------
+// frame of segment k from the frame of segment k-1; joint cos/sin from LDS slot `src`
+DEV void advance_frame(const mvk_model* __restrict__ M, const Smem& sm, int src, int k, double R[9], double p[3]) {
+  double pn[3];
+  xform(R, p, M->seg_t[k][0], M->seg_t[k][1], M->seg_t[k][2], pn);
+  p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+  const int jn = M->seg_joint[k];
+  const double c = sm.cs[(2 * jn) * kBlock + src], s = sm.cs[(2 * jn + 1) * kBlock + src];
+  rot_cols_dyn(R, M->seg_axis[k], c, s);
+}
+
+// pose of primitive q (wave-uniform) riding on the segment frame (R, p): world
+// centre pc and, when WANT_ROT, world rotation PR (collision_avoidance.cpp:123-132:
+// root * link * collision origin)
+template <bool GIMBAL, bool WANT_ROT>
+DEV void prim_pose(const mvk_model* __restrict__ M, int q, const double R[9], const double p[3], double pc[3], double PR[9]) {
+  double B[9], bp[3];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = Rw[k];
-    p[0] = st[0]; p[1] = st[1]; p[2] = st[2];
-#pragma unroll 1
-    for (int k = 0; k < NS; ++k) {
-      if (k > 0) {
-        double pn[3];
-        xform(R, p, M->seg_t[k][0], M->seg_t[k][1], M->seg_t[k][2], pn);
-        p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
-        const int jn = M->seg_joint[k];
-        const double c = sm.cs[(2 * jn) * kBlock + tid], s = sm.cs[(2 * jn + 1) * kBlock + tid];
-        rot_cols_dyn(R, M->seg_axis[k], c, s);
+  for (int e = 0; e < 9; ++e) B[e] = R[e];
+  bp[0] = p[0]; bp[1] = p[1]; bp[2] = p[2];
+  if (GIMBAL && M->prim_frame[q] != MVK_FRAME_SEG) {
+    const int i = M->prim_rotor[q];
+    double o[3];
+    xform(R, p, M->rotor_pos[i][0], M->rotor_pos[i][1], M->rotor_pos[i][2], o);
+    bp[0] = o[0]; bp[1] = o[1]; bp[2] = o[2];
+    double cr, sr, cp, sp;
+    gimbal_cs(R[6], R[7], R[8], cr, sr, cp, sp);
+    rot_cols<0>(B, cr, sr);
+    if (M->prim_frame[q] == MVK_FRAME_GIMBAL_PITCH) rot_cols<1>(B, cp, sp);
+  }
+  xform(B, bp, M->prim_pos[q][0], M->prim_pos[q][1], M->prim_pos[q][2], pc);
+  if (WANT_ROT) {
+    double Lr[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Lr[e] = M->prim_rot[q][e];
+    mat_mul(B, Lr, PR);
+  }
+}
+
+DEV void to_box_frame(const DevObs& O, const double pc[3], double t[3]) {
+  const double dx = pc[0] - O.c[0], dy = pc[1] - O.c[1], dz = pc[2] - O.c[2];
+  t[0] = fma(O.R[0], dx, fma(O.R[3], dy, O.R[6] * dz));
+  t[1] = fma(O.R[1], dx, fma(O.R[4], dy, O.R[7] * dz));
+  t[2] = fma(O.R[2], dx, fma(O.R[5], dy, O.R[8] * dz));
+}
+
+// squared distance from a point (already in the box frame) to the box
+DEV double point_box_dist2(const double t[3], const double h[3]) {
+  const double e0 = excess_abs(t[0], h[0]), e1 = excess_abs(t[1], h[1]), e2 = excess_abs(t[2], h[2]);
+  return fma(e0, e0, fma(e1, e1, e2 * e2));
+}
+
+// exact test of one primitive against one box (primitive kind is wave-uniform); t = primitive
+// centre in the box frame.  SIGNED: signed distance; otherwise only the sign is meaningful.
+template <bool SIGNED>
+DEV double narrow(int type, const double PR[9], double d0, double d1, double d2, const DevObs& O, const double t[3]) {
+  double d;
+  if (type == MVK_PRIM_CAPSULE) {
+    // axis = local z in world = third column of PR, into the box frame
+    double a[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[c] = fma(O.R[c], PR[2], fma(O.R[3 + c], PR[5], O.R[6 + c] * PR[8]));
+    double p0[3], dd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { p0[c] = fma(-d1, a[c], t[c]); dd[c] = 2.0 * d1 * a[c]; }
+    const double s2 = seg_box_dist2(p0, dd, O.h);
+    if (SIGNED) d = sqrt(s2) - d0;
+    else d = (s2 <= d0 * d0) ? 0.0 : 1.0;
+  } else {
+    // box: primitive axes in the obstacle frame  Rr = O.R^T * PR
+    double Rr[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        Rr[3 * r + c] = fma(O.R[r], PR[c], fma(O.R[3 + r], PR[3 + c], O.R[6 + r] * PR[6 + c]));
+    const double a[3] = {d0, d1, d2};
+    if (SIGNED) {
+      d = box_box_sat<true>(t, Rr, a, O.h);
+      if (d > 0.0) {
+        // exact separation: closest features always include a point on an edge
+        double s2 = box_edges_to_box2(t, Rr, a, O.h);
+        double Rt[9], tb[3];  // obstacle in the primitive's frame
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Rt[3 * r + c] = Rr[3 * c + r];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) tb[r] = -fma(Rr[r], t[0], fma(Rr[3 + r], t[1], Rr[6 + r] * t[2]));
+        s2 = fmin(s2, box_edges_to_box2(tb, Rt, O.h, a));
+        d = sqrt(s2);
       }
-      // pose of primitive q riding on the current segment frame (R, p)
-      auto prim_pose = [&](int q, double pc[3], double PR[9]) {
-        double B[9], bp[3];
+    } else {
+      d = box_box_sat<false>(t, Rr, a, O.h);
+    }
+  }
+  return d;
+}
+
+// level 0 of the flag path: the broadphase grid (mvk_grid.cpp).  The cell holding c lists
+// every box within the largest segment radius of any point of the cell; [gb, ge) are its
+// groups of kGridGroup ids.  Points outside the grid volume have no box within that radius.
+DEV void grid_cell(const GridDev& G, const double c[3], bool on, unsigned& gb, unsigned& ge) {
+  const double gx = (c[0] - G.origin[0]) * G.inv_h, gy = (c[1] - G.origin[1]) * G.inv_h, gz = (c[2] - G.origin[2]) * G.inv_h;
+  const bool inside = on && gx >= 0.0 && gy >= 0.0 && gz >= 0.0 && gx < static_cast<double>(G.n[0]) &&
+                      gy < static_cast<double>(G.n[1]) && gz < static_cast<double>(G.n[2]);
+  gb = 0; ge = 0;
+  if (inside) {
+    const unsigned cell = (static_cast<unsigned>(static_cast<int>(gz)) * G.n[1] + static_cast<unsigned>(static_cast<int>(gy))) * G.n[0] +
+                          static_cast<unsigned>(static_cast<int>(gx));
+    gb = G.start[cell];
+    ge = G.start[cell + 1];
+  }
+}
+
+// fp32 squared distance from a point to a world box
+DEV float point_box_dist2_f32(const DevObsF& F, float x, float y, float z) {
+  const float dx = x - F.c[0], dy = y - F.c[1], dz = z - F.c[2];
+  const float e0 = fmaxf(fabsf(fmaf(F.R[0], dx, fmaf(F.R[3], dy, F.R[6] * dz))) - F.h[0], 0.0f);
+  const float e1 = fmaxf(fabsf(fmaf(F.R[1], dx, fmaf(F.R[4], dy, F.R[7] * dz))) - F.h[1], 0.0f);
+  const float e2 = fmaxf(fabsf(fmaf(F.R[2], dx, fmaf(F.R[5], dy, F.R[8] * dz))) - F.h[2], 0.0f);
+  return fmaf(e0, e0, fmaf(e1, e1, e2 * e2));
+}
+
+// The fp32 classification of a (primitive, box) pair by the primitive's centre distance.
+// f32_delta bounds the fp32 evaluation error of that distance for coordinates within
+// f32_range, so
+//   l2 <= hit2  =>  the ball inscribed in the primitive truly touches the box   (collision)
+//   l2 >  may2  =>  the ball circumscribing the primitive truly misses the box  (no contact)
+// and only the pairs in between need fp64.  Outside f32_range nothing is decided in fp32.
+struct PrimF32 {
+  float x[kSegPrimMax], y[kSegPrimMax], z[kSegPrimMax], hit2[kSegPrimMax], may2[kSegPrimMax];
+};
+
+template <bool GIMBAL>
+DEV void prims_f32(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X, int pb, int np,
+                   const double R[9], const double p[3], bool f32_safe, PrimF32& F) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) B[e] = R[e];
-        bp[0] = p[0]; bp[1] = p[1]; bp[2] = p[2];
-        if (S::kGimbal && M->prim_frame[q] != MVK_FRAME_SEG) {
-          const int i = M->prim_rotor[q];
-          double o[3];
-          xform(R, p, M->rotor_pos[i][0], M->rotor_pos[i][1], M->rotor_pos[i][2], o);
-          bp[0] = o[0]; bp[1] = o[1]; bp[2] = o[2];
-          double cr, sr, cp, sp;
-          gimbal_cs(R[6], R[7], R[8], cr, sr, cp, sp);
-          rot_cols<0>(B, cr, sr);
-          if (M->prim_frame[q] == MVK_FRAME_GIMBAL_PITCH) rot_cols<1>(B, cp, sp);
-        }
-        xform(B, bp, M->prim_pos[q][0], M->prim_pos[q][1], M->prim_pos[q][2], pc);
-        double Lr[9];
+  for (int j = 0; j < kSegPrimMax; ++j) {
+    F.x[j] = F.y[j] = F.z[j] = 0.0f;
+    F.hit2[j] = -1.0f;
+    F.may2[j] = -1.0f;
+    if (j < np) {
+      const int q = X->prim_order[pb + j];
+      double pc[3];
+      prim_pose<GIMBAL, false>(M, q, R, p, pc, nullptr);
+      F.x[j] = static_cast<float>(pc[0]); F.y[j] = static_cast<float>(pc[1]); F.z[j] = static_cast<float>(pc[2]);
+      const float rin = static_cast<float>(X->prim_inner[q]) * 0.999999f - A.f32_delta;
+      const float rb = (static_cast<float>(X->prim_bound[q]) + A.f32_delta) * 1.000001f;
+      F.hit2[j] = (f32_safe && rin > 0.0f) ? rin * rin : -1.0f;
+      F.may2[j] = f32_safe ? rb * rb : INFINITY;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
+// flag path, phase 1: fp32 screen of every (primitive, box) pair the grid lists
+// ------------------------------------------------------------------------
+// hit   : some pair is a certain collision            -> the state is decided (invalid)
+// maybe : some pair needs the exact fp64 test         -> undecided unless hit
+// neither                                            -> no contact, decided
+template <int ROBOT, int NL>
+DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                        const DevObsF* __restrict__ obsf, const double pos[3], const double Rw[9], const Smem& sm,
+                        bool live, bool& hit, bool& maybe) {
+  using S = Shape<ROBOT, NL>;
+  const int tid = threadIdx.x;
+  const bool f32_safe = fmax(fabs(pos[0]), fmax(fabs(pos[1]), fabs(pos[2]))) + X->reach <= A.f32_range;
+  double R[9], p[3];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) Lr[e] = M->prim_rot[q][e];
-        mat_mul(B, Lr, PR);
-      };
-      // exact signed test of one primitive against one box (kind is wave-uniform)
-      auto narrow = [&](int type, const double pc[3], const double PR[9], double d0, double d1, double d2,
-                        const DevObs& O, const double t[3]) -> double {
-        double d;
-        if (type == MVK_PRIM_CAPSULE) {
-          // axis = local z in world = third column of PR, into the box frame
-          double a[3];
+  for (int k = 0; k < 9; ++k) R[k] = Rw[k];
+  p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
+  hit = false; maybe = false;
+#pragma unroll 1
+  for (int k = 0; k < S::kSeg; ++k) {
+    if (k > 0) advance_frame(M, sm, tid, k, R, p);
+    const int pb = X->seg_prim_begin[k], np = X->seg_prim_begin[k + 1] - pb;
+    if (np == 0) continue;
+    PrimF32 Pf;
+    prims_f32<S::kGimbal>(A, M, X, pb, np, R, p, f32_safe, Pf);
+    double sc[3];
+    xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
+    unsigned gb, ge;
+    grid_cell(A.grid, sc, live && !hit, gb, ge);
+#pragma unroll 1
+    for (unsigned g = gb; __any(g < ge); ++g) {
+      PROF_WAVE(5);
+      PROF_LANES(6, g < ge);
+      if (g < ge) {
+        const uint2 w = *reinterpret_cast<const uint2*>(A.grid.items + static_cast<size_t>(g) * kGridGroup);
+        const unsigned ids[kGridGroup] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+        DevObsF F[kGridGroup];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) a[c] = fma(O.R[c], PR[2], fma(O.R[3 + c], PR[5], O.R[6 + c] * PR[8]));
-          double p0[3], dd[3];
+        for (int c = 0; c < kGridGroup; ++c) F[c] = obsf[ids[c] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[c]];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) { p0[c] = fma(-d1, a[c], t[c]); dd[c] = 2.0 * d1 * a[c]; }
-          const double s2 = seg_box_dist2(p0, dd, O.h);
-          if (FULL) d = sqrt(s2) - d0;
-          else d = (s2 <= d0 * d0) ? 0.0 : 1.0;
-        } else {
-          // box: primitive axes in the obstacle frame  Rr = O.R^T * PR
-          double Rr[9];
+        for (int c = 0; c < kGridGroup; ++c) {
+          const bool real = ids[c] != kGridNone;
 #pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-              Rr[3 * r + c] = fma(O.R[r], PR[c], fma(O.R[3 + r], PR[3 + c], O.R[6 + r] * PR[6 + c]));
-          const double a[3] = {d0, d1, d2};
-          if (FULL) {
-            d = box_box_sat<true>(t, Rr, a, O.h);
-            if (d > 0.0) {
-              // exact separation: closest features always include a point on an edge
-              double s2 = box_edges_to_box2(t, Rr, a, O.h);
-              double Rt[9], tb[3];  // obstacle in the primitive's frame
-#pragma unroll
-              for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Rt[3 * r + c] = Rr[3 * c + r];
-#pragma unroll
-              for (int r = 0; r < 3; ++r) tb[r] = -fma(Rr[r], t[0], fma(Rr[3 + r], t[1], Rr[6 + r] * t[2]));
-              s2 = fmin(s2, box_edges_to_box2(tb, Rt, O.h, a));
-              d = sqrt(s2);
+          for (int j = 0; j < kSegPrimMax; ++j) {
+            if (j < np) {
+              const float l2 = point_box_dist2_f32(F[c], Pf.x[j], Pf.y[j], Pf.z[j]);
+              hit = hit || (real && l2 <= Pf.hit2[j]);
+              maybe = maybe || (real && l2 <= Pf.may2[j]);
             }
-          } else {
-            d = box_box_sat<false>(t, Rr, a, O.h);
           }
         }
-        return d;
-      };
-      auto to_box_frame = [&](const DevObs& O, const double pc[3], double t[3]) {
-        const double dx = pc[0] - O.c[0], dy = pc[1] - O.c[1], dz = pc[2] - O.c[2];
-        t[0] = fma(O.R[0], dx, fma(O.R[3], dy, O.R[6] * dz));
-        t[1] = fma(O.R[1], dx, fma(O.R[4], dy, O.R[7] * dz));
-        t[2] = fma(O.R[2], dx, fma(O.R[5], dy, O.R[8] * dz));
-      };
-      const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
+        if (hit) ge = gb;  // decided: stop fetching
+      }
+    }
+    if (!__any(live && !hit)) break;
+  }
+  hit = hit && live;
+  maybe = maybe && live;
+}
 
-      if (!FULL) {
-        // ===== flag path: grid lookup + two-level cull ========================
-        // level 0: the broadphase grid (mvk_grid.cpp).  The cell holding the centre of
-        // this segment's bounding sphere lists every box within the largest segment
-        // radius of any point of the cell: one index computation + one contiguous list.
-        // level 1 (fp32): sphere vs listed box; survivors go to this lane's LDS list.
-        // The fp32 test is conservative: its radius is inflated by f32_delta, a bound on
-        // the fp32 evaluation error for coordinates within f32_range (lanes outside that
-        // range keep every listed box).  level 2 (fp64, per lane): exact centre test +
-        // narrowphase of each primitive of the segment against the surviving boxes only.
-        if (pb == pe) continue;
-        double sc[3];
-        xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
-        const float sx = static_cast<float>(sc[0]), sy = static_cast<float>(sc[1]), sz = static_cast<float>(sc[2]);
-        const float thr = (static_cast<float>(X->seg_sph[k][3]) + A.f32_delta) * 1.000001f;
-        const float thr2 = f32_safe ? thr * thr : INFINITY;
-        const GridDev& G = A.grid;
-        const double gx = (sc[0] - G.origin[0]) * G.inv_h, gy = (sc[1] - G.origin[1]) * G.inv_h,
-                     gz = (sc[2] - G.origin[2]) * G.inv_h;
-        const bool inside = live && gx >= 0.0 && gy >= 0.0 && gz >= 0.0 && gx < static_cast<double>(G.n[0]) &&
-                            gy < static_cast<double>(G.n[1]) && gz < static_cast<double>(G.n[2]);
-        unsigned gb = 0, ge = 0;
-        if (inside) {
-          const unsigned cell = (static_cast<unsigned>(static_cast<int>(gz)) * G.n[1] + static_cast<unsigned>(static_cast<int>(gy))) * G.n[0] +
-                                static_cast<unsigned>(static_cast<int>(gx));
-          const uint2 se = *reinterpret_cast<const uint2*>(G.start + cell);  // start[cell], start[cell + 1]
-          gb = se.x; ge = se.y;
-        }
-        int cnt = 0;
+// ------------------------------------------------------------------------
+// flag path, phase 2: exact fp64 tests for the states phase 1 left undecided
+// ------------------------------------------------------------------------
+// Runs on lanes compacted over the block: `src` is the block slot of the state this
+// lane re-evaluates (its joint cos/sin are in LDS slot src), `tid` owns the lists.
+template <int ROBOT, int NL>
+DEV bool collide_exact(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                       const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf, const double pos[3],
+                       const double Rw[9], const Smem& sm, int src, bool live) {
+  using S = Shape<ROBOT, NL>;
+  const int tid = threadIdx.x;
+  const bool f32_safe = fmax(fabs(pos[0]), fmax(fabs(pos[1]), fabs(pos[2]))) + X->reach <= A.f32_range;
+  double R[9], p[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = Rw[k];
+  p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
+  bool hit = false;
 #pragma unroll 1
-        for (unsigned g = gb; __any(g < ge); ++g) {
-          if (g < ge) {
-            const uint2 w = *reinterpret_cast<const uint2*>(G.items + static_cast<size_t>(g) * kGridGroup);
-            const unsigned ids[kGridGroup] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
-            DevObsF F[kGridGroup];
+  for (int k = 0; k < S::kSeg; ++k) {
+    if (k > 0) advance_frame(M, sm, src, k, R, p);
+    const int pb = X->seg_prim_begin[k], np = X->seg_prim_begin[k + 1] - pb;
+    if (np == 0) continue;
+    PrimF32 Pf;
+    prims_f32<S::kGimbal>(A, M, X, pb, np, R, p, f32_safe, Pf);
+    double sc[3];
+    xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
+    unsigned gb, ge;
+    grid_cell(A.grid, sc, live && !hit, gb, ge);
+    // level 1: the pairs fp32 cannot clear go to per-primitive lists in LDS
+    int cnt[kSegPrimMax];
 #pragma unroll
-            for (int j = 0; j < kGridGroup; ++j) F[j] = obsf[ids[j] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[j]];
+    for (int j = 0; j < kSegPrimMax; ++j) cnt[j] = 0;
+#pragma unroll 1
+    for (unsigned g = gb; __any(g < ge); ++g) {
+      PROF_WAVE(8);
+      if (g < ge) {
+        const uint2 w = *reinterpret_cast<const uint2*>(A.grid.items + static_cast<size_t>(g) * kGridGroup);
+        const unsigned ids[kGridGroup] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+        DevObsF F[kGridGroup];
 #pragma unroll
-            for (int j = 0; j < kGridGroup; ++j) {
-              const float dx = sx - F[j].c[0], dy = sy - F[j].c[1], dz = sz - F[j].c[2];
-              const float e0 = fmaxf(fabsf(fmaf(F[j].R[0], dx, fmaf(F[j].R[3], dy, F[j].R[6] * dz))) - F[j].h[0], 0.0f);
-              const float e1 = fmaxf(fabsf(fmaf(F[j].R[1], dx, fmaf(F[j].R[4], dy, F[j].R[7] * dz))) - F[j].h[1], 0.0f);
-              const float e2 = fmaxf(fabsf(fmaf(F[j].R[2], dx, fmaf(F[j].R[5], dy, F[j].R[8] * dz))) - F[j].h[2], 0.0f);
-              const float l2 = fmaf(e0, e0, fmaf(e1, e1, e2 * e2));
-              if (ids[j] != kGridNone && l2 <= thr2) {
-                if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ids[j]);
-                ++cnt;
+        for (int c = 0; c < kGridGroup; ++c) F[c] = obsf[ids[c] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[c]];
+#pragma unroll
+        for (int c = 0; c < kGridGroup; ++c) {
+#pragma unroll
+          for (int j = 0; j < kSegPrimMax; ++j) {
+            if (j < np) {
+              const float l2 = point_box_dist2_f32(F[c], Pf.x[j], Pf.y[j], Pf.z[j]);
+              if (ids[c] != kGridNone && l2 <= Pf.may2[j]) {
+                if (cnt[j] < kPairCap) sm.list[(j * kPairCap + cnt[j]) * kBlock + tid] = static_cast<unsigned short>(ids[c]);
+                ++cnt[j];
               }
             }
-          }
-        }
-        const bool overflow = cnt > kListCap;  // fall back to this cell's whole list for this segment
-        const int ntodo = live ? (overflow ? static_cast<int>(ge - gb) * kGridGroup : cnt) : 0;
-        if (__any(ntodo > 0)) {
-#pragma unroll 1
-          for (int qi = pb; qi < pe; ++qi) {
-            const int q = X->prim_order[qi];
-            const int type = M->prim_type[q];
-            double pc[3], PR[9];
-            prim_pose(q, pc, PR);
-            const double rb = X->prim_bound[q], rin = X->prim_inner[q];
-            const double rb2 = rb * rb, rin2 = rin * rin;
-            const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
-            int todo = live ? ntodo : 0;
-#pragma unroll 1
-            for (int e = 0; __any(e < todo); ++e) {
-              if (e < todo) {
-                const unsigned ob = overflow ? G.items[static_cast<size_t>(gb) * kGridGroup + e] : sm.list[e * kBlock + tid];
-                if (ob != kGridNone) {
-                  const DevObs O = obs[ob];
-                  double t[3];
-                  to_box_frame(O, pc, t);
-                  const double e0 = excess_abs(t[0], O.h[0]), e1 = excess_abs(t[1], O.h[1]), e2 = excess_abs(t[2], O.h[2]);
-                  const double l2 = fma(e0, e0, fma(e1, e1, e2 * e2));
-                  bool hit = l2 <= rin2;  // a ball inside the primitive already touches the box
-                  if (!hit && type != MVK_PRIM_SPHERE && l2 <= rb2) hit = narrow(type, pc, PR, d0, d1, d2, O, t) <= 0.0;
-                  if (hit) { mind = 0.0; live = false; todo = 0; }
-                }
-              }
-            }
-          }
-        }
-        if (!__any(live)) break;
-        continue;
-      }
-
-      // ===== full path: exact minimum distance over every (primitive, box) pair =====
-#pragma unroll 1
-      for (int qi = pb; qi < pe; ++qi) {
-        const int q = X->prim_order[qi];
-        const int type = M->prim_type[q];
-        double pc[3], PR[9];
-        prim_pose(q, pc, PR);
-        const double rb = X->prim_bound[q];
-        const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
-
-        // -- broadphase sweep: centre-to-box distance vs bounding radius -------
-        // obstacle boxes are read at wave-uniform addresses (scalar loads -> SGPRs)
-        auto centre_dist2 = [&](const DevObs& O) {
-          const double dx = pc[0] - O.c[0], dy = pc[1] - O.c[1], dz = pc[2] - O.c[2];
-          const double e0 = excess_abs(fma(O.R[0], dx, fma(O.R[3], dy, O.R[6] * dz)), O.h[0]);
-          const double e1 = excess_abs(fma(O.R[1], dx, fma(O.R[4], dy, O.R[7] * dz)), O.h[1]);
-          const double e2 = excess_abs(fma(O.R[2], dx, fma(O.R[5], dy, O.R[8] * dz)), O.h[2]);
-          return fma(e0, e0, fma(e1, e1, e2 * e2));
-        };
-        int cnt = 0;
-        // pass 1: the primitive's origin lies inside it, so min_ob dist(origin, box)
-        // bounds this primitive's separation from above
-        double best2 = INFINITY;
-#pragma unroll 2
-        for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
-        if (type == MVK_PRIM_SPHERE) {
-          mind = fmin(mind, sqrt(best2) - d0);  // exact for a sphere
-        } else {
-          // pass 2: keep pairs whose lower bound (centre distance - bounding radius)
-          // can still undercut the running minimum, and every possibly-touching pair
-          const double thr = rb + fmax(fmin(mind, sqrt(best2)), 0.0);
-          const double thr2 = thr * thr;
-#pragma unroll 2
-          for (int ob = 0; ob < A.n_obs; ++ob) {
-            if (live && centre_dist2(obs[ob]) <= thr2) {
-              if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
-              ++cnt;
-            }
-          }
-        }
-        // -- narrowphase drain: kind is wave-uniform, list length is per lane ---
-        const bool overflow = cnt > kListCap;
-        int todo = live ? (overflow ? A.n_obs : cnt) : 0;
-        if (type == MVK_PRIM_SPHERE) todo = 0;
-#pragma unroll 1
-        for (int e = 0; __any(e < todo); ++e) {
-          if (e < todo) {
-            // on overflow fall back to testing every obstacle for this primitive
-            const int ob = overflow ? e : sm.list[e * kBlock + tid];
-            const DevObs O = obs[ob];
-            double t[3];
-            to_box_frame(O, pc, t);
-            mind = fmin(mind, narrow(type, pc, PR, d0, d1, d2, O, t));
           }
         }
       }
     }
+    // level 2: exact centre test + narrowphase, one primitive (kind wave-uniform) at a time
+#pragma unroll
+    for (int j = 0; j < kSegPrimMax; ++j) {
+      if (j >= np) continue;
+      const bool overflow = cnt[j] > kPairCap;  // fall back to this cell's whole list
+      int todo = (live && !hit) ? (overflow ? static_cast<int>(ge - gb) * kGridGroup : cnt[j]) : 0;
+      if (!__any(todo > 0)) continue;
+      const int q = X->prim_order[pb + j];
+      const int type = M->prim_type[q];
+      double pc[3], PR[9];
+      prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
+      const double rb = X->prim_bound[q], rin = X->prim_inner[q];
+      const double rb2 = rb * rb, rin2 = rin * rin;
+      const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+#pragma unroll 1
+      for (int e = 0; __any(e < todo); ++e) {
+        PROF_WAVE(9);
+        PROF_LANES(10, e < todo);
+        if (e < todo) {
+          const unsigned ob = overflow ? A.grid.items[static_cast<size_t>(gb) * kGridGroup + e]
+                                       : sm.list[(j * kPairCap + e) * kBlock + tid];
+          if (ob != kGridNone) {
+            const DevObs O = obs[ob];
+            double t[3];
+            to_box_frame(O, pc, t);
+            const double l2 = point_box_dist2(t, O.h);
+            bool h = l2 <= rin2;  // a ball inside the primitive already touches the box
+#ifdef MVK_PROF
+            { const bool nw = !h && type != MVK_PRIM_SPHERE && l2 <= rb2; const unsigned long long b = __ballot(nw);
+              if (b && (threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { atomicAdd(&g_prof[11], 1ull); atomicAdd(&g_prof[12], (unsigned long long)__popcll(b)); } }
+#endif
+            if (!h && type != MVK_PRIM_SPHERE && l2 <= rb2) h = narrow<false>(type, PR, d0, d1, d2, O, t) <= 0.0;
+            if (h) { hit = true; todo = 0; }
+          }
+        }
+      }
+    }
+    if (!__any(live && !hit)) break;
   }
-  out.min_dist = (A.do_coll && finite) ? mind : INFINITY;
-  out.collision = A.do_coll && (mind <= 0.0);
-  out.valid = finite && (!A.do_stab || out.stable) && !out.collision;
-  out.band = !finite || (A.do_stab && fabs(margin) <= A.eps_margin) ||
-             (FULL && A.do_coll && fabs(mind) <= A.eps_dist);
-  if (!finite) { out.margin = -INFINITY; out.min_dist = NAN; out.stable = false; out.collision = false; }
+  return hit && live;
+}
+
+// ------------------------------------------------------------------------
+// full path: exact minimum distance over every (primitive, box) pair
+// ------------------------------------------------------------------------
+template <int ROBOT, int NL>
+DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                        const DevObs* __restrict__ obs, const double pos[3], const double Rw[9], const Smem& sm,
+                        bool live) {
+  using S = Shape<ROBOT, NL>;
+  const int tid = threadIdx.x;
+  double R[9], p[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = Rw[k];
+  p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
+  double mind = INFINITY;
+#pragma unroll 1
+  for (int k = 0; k < S::kSeg; ++k) {
+    if (k > 0) advance_frame(M, sm, tid, k, R, p);
+    const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
+#pragma unroll 1
+    for (int qi = pb; qi < pe; ++qi) {
+      const int q = X->prim_order[qi];
+      const int type = M->prim_type[q];
+      double pc[3], PR[9];
+      prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
+      const double rb = X->prim_bound[q];
+      const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+
+      // -- broadphase sweep: centre-to-box distance vs bounding radius -------
+      // obstacle boxes are read at wave-uniform addresses (scalar loads -> SGPRs)
+      auto centre_dist2 = [&](const DevObs& O) {
+        double t[3];
+        to_box_frame(O, pc, t);
+        return point_box_dist2(t, O.h);
+      };
+      int cnt = 0;
+      // pass 1: the primitive's origin lies inside it, so min_ob dist(origin, box)
+      // bounds this primitive's separation from above
+      double best2 = INFINITY;
+#pragma unroll 2
+      for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
+      if (type == MVK_PRIM_SPHERE) {
+        mind = fmin(mind, sqrt(best2) - d0);  // exact for a sphere
+      } else {
+        // pass 2: keep pairs whose lower bound (centre distance - bounding radius)
+        // can still undercut the running minimum, and every possibly-touching pair
+        const double thr = rb + fmax(fmin(mind, sqrt(best2)), 0.0);
+        const double thr2 = thr * thr;
+#pragma unroll 2
+        for (int ob = 0; ob < A.n_obs; ++ob) {
+          if (live && centre_dist2(obs[ob]) <= thr2) {
+            if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
+            ++cnt;
+          }
+        }
+      }
+      // -- narrowphase drain: kind is wave-uniform, list length is per lane ---
+      const bool overflow = cnt > kListCap;
+      int todo = live ? (overflow ? A.n_obs : cnt) : 0;
+      if (type == MVK_PRIM_SPHERE) todo = 0;
+#pragma unroll 1
+      for (int e = 0; __any(e < todo); ++e) {
+        if (e < todo) {
+          // on overflow fall back to testing every obstacle for this primitive
+          const int ob = overflow ? e : sm.list[e * kBlock + tid];
+          const DevObs O = obs[ob];
+          double t[3];
+          to_box_frame(O, pc, t);
+          mind = fmin(mind, narrow<true>(type, PR, d0, d1, d2, O, t));
+        }
+      }
+    }
+  }
+  return mind;
 }
 
 // ------------------------------------------------------------------------
@@ -807,28 +969,20 @@ DEV void unpack_ompl(const EvalArgs& A, const double* s, double* st) {
   }
 }
 
-template <int ROBOT, int NL, bool FULL, bool EDGE>
-__global__ void __launch_bounds__(kBlock)
-validity_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
-                const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf) {
-  using S = Shape<ROBOT, NL>;
-  constexpr int NJ = S::kJoint;
-  __shared__ double sm_cs[2 * NJ * kBlock];
-  __shared__ unsigned short sm_list[kListCap * kBlock];
-  Smem sm{sm_cs, sm_list};
-
-  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  const bool in_range = gi < A.n;
-  const uint64_t li = in_range ? gi : (A.n - 1);  // clamp: out-of-range lanes redo the last state
-
-  double st[7 + NJ];
-  uint64_t edge = 0;
-  int step = 0, nd_e = 1;
+// State of global lane index li: a SoA batch row set, or step j of edge e densified in place
+// (lane -> (edge, step): step j in 1..nd tests interp(s1, s2, j/nd); j = nd is s2 itself).
+// WANT_JOINTS = false skips the joint rows (phase 2 of the flag path only needs the root pose).
+template <int NJ, bool EDGE, bool WANT_JOINTS>
+DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t& edge, int& step) {
+  edge = 0;
+  step = 0;
   if (!EDGE) {
     const double* __restrict__ src = A.soa;
     if (A.layout == MVK_LAYOUT_POSE7) {
 #pragma unroll
-      for (int r = 0; r < 7 + NJ; ++r) st[r] = src[r * A.ld + li];
+      for (int r = 0; r < 7; ++r) st[r] = src[r * A.ld + li];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) st[7 + j] = WANT_JOINTS ? src[(7 + j) * A.ld + li] : 0.0;
       if (A.planning_mode == MVK_MODE_ONLY_JOINTS) {
         st[0] = st[1] = st[2] = st[3] = st[4] = st[5] = 0.0; st[6] = 1.0;
       }
@@ -842,13 +996,13 @@ validity_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
 #pragma unroll
       for (int r = 0; r < 7; ++r) s[r] = (r < nb) ? src[r * A.ld + li] : 0.0;
       unpack_ompl<NJ>(A, s, st);
-      if (A.planning_mode != MVK_MODE_ONLY_BASE) {
+      if (WANT_JOINTS && A.planning_mode != MVK_MODE_ONLY_BASE) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) st[7 + j] = src[(nb + j) * A.ld + li];
       }
     }
   } else {
-    // lane -> (edge, step): step j in 1..nd tests interp(s1, s2, j/nd); j = nd is s2 itself
+    int nd_e;
     if (A.nd == nullptr) {
       nd_e = A.nd_uniform;
       edge = li / static_cast<uint64_t>(nd_e);
@@ -885,7 +1039,7 @@ validity_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
       }
     }
     unpack_ompl<NJ>(A, s, st);
-    if (A.planning_mode != MVK_MODE_ONLY_BASE) {
+    if (WANT_JOINTS && A.planning_mode != MVK_MODE_ONLY_BASE) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const double ja = A.s1[(nb + j) * A.ld + edge], jb = A.s2[(nb + j) * A.ld + edge];
@@ -893,38 +1047,182 @@ validity_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------
+// Flag path = two launches on one stream.
+//   screen_kernel : one lane per state.  Walk 1 (model update, stability) and the fp32 screen of
+//                   the collision pairs.  Writes every output; a state the screen cannot decide
+//                   is written as "valid so far" and its index is appended to the ctx's queue.
+//   exact_kernel  : one lane per queue entry (dense waves instead of the few undecided lanes of
+//                   every wave).  Exact fp64 tests; a collision clears the state's flag / mask bit
+//                   (or lowers first_invalid of its edge).
+// Full path = full_kernel: exact minimum distance, margins, details and statistics, no early exit.
+template <int ROBOT, int NL, bool EDGE>
+__global__ void __launch_bounds__(kBlock)
+screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+              const DevObsF* __restrict__ obsf) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ double sm_cs[2 * NJ * kBlock];
+  Smem sm{(lds_double*)sm_cs, nullptr};
+
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);  // clamp: out-of-range lanes redo the last state
+  if (gi == 0) *A.queue_count_next = 0u;          // the counter the NEXT call on this ctx appends to
+
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, EDGE, true>(A, li, st, edge, step);
 
   StateOut o;
-  double thrust[NL];
-  eval_state<ROBOT, NL, FULL>(A, M, X, obs, obsf, st, sm, li, o, FULL ? thrust : nullptr);
+  double Rw[9];
+  bool finite;
+  model_update<ROBOT, NL, false>(A, M, X, st, sm, li, o, Rw, finite, nullptr);
 
+  // lanes whose verdict cannot change any more (unstable, or not finite) generate no work
+  const bool live = finite && A.do_coll && A.n_obs > 0 && (!A.do_stab || o.stable);
+  bool hit = false, maybe = false;
+  if (__any(live)) collide_screen<ROBOT, NL>(A, M, X, obsf, st, Rw, sm, live, hit, maybe);
+  const bool undecided = in_range && live && !hit && maybe;
+  PROF_LANES(0, true); PROF_LANES(1, live); PROF_LANES(2, hit); PROF_LANES(3, undecided); PROF_LANES(4, live && !hit && !maybe);
+
+  // append the undecided states of this block to the queue: one atomic per block
+  {
+    __shared__ unsigned sm_wave_cnt[kBlock / 64];
+    __shared__ unsigned sm_base;
+    const unsigned long long bal = __ballot(undecided);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm_wave_cnt[wv] = static_cast<unsigned>(__popcll(bal));
+    __syncthreads();
+    unsigned before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+      const unsigned c = sm_wave_cnt[w];
+      before += (w < wv) ? c : 0u;
+      total += c;
+    }
+    if (total > 0) {  // block-uniform
+      if (threadIdx.x == 0) sm_base = atomicAdd(A.queue_count, total);
+      __syncthreads();
+      if (undecided) A.queue[sm_base + before + __popcll(bal & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(gi);
+    }
+  }
+
+  const bool valid = finite && (!A.do_stab || o.stable) && !hit;
+  const bool band = !finite || (A.do_stab && fabs(o.margin) <= A.eps_margin);
   if (!EDGE) {
     if (in_range) {
-      if (A.flags) A.flags[gi] = o.valid ? 1 : 0;
-      if (A.band) A.band[gi] = o.band ? 1 : 0;
-      if (FULL) {
-        if (A.min_dist) A.min_dist[gi] = o.min_dist;
-        if (A.margin) A.margin[gi] = o.margin;
-        if (A.fc_t_min) A.fc_t_min[gi] = o.fc_t_min;
-        if (A.fc_rp_min) A.fc_rp_min[gi] = o.fc_rp_min;
-        if (A.rp_margin) A.rp_margin[gi] = o.rp_margin;
-        if (A.thrust) {
-#pragma unroll
-          for (int i = 0; i < NL; ++i) A.thrust[i * A.ld + gi] = thrust[i];
-        }
-      }
+      if (A.flags) A.flags[gi] = valid ? 1 : 0;
+      if (A.band) A.band[gi] = band ? 1 : 0;
     }
     if (A.mask) {
-      const unsigned long long bal = __ballot(in_range && o.valid);
+      const unsigned long long bal = __ballot(in_range && valid);
       if ((threadIdx.x & 63) == 0 && (gi - (gi & 63)) < A.n) A.mask[gi >> 6] = bal;
     }
   } else {
-    if (in_range && !o.valid) atomicMin(&A.first_invalid[edge], step);
-    if (A.band && in_range && o.band) A.band[edge] = 1;
+    if (in_range && !valid) atomicMin(&A.first_invalid[edge], step);
+    if (A.band && in_range && band) A.band[edge] = 1;
+  }
+}
+
+template <int ROBOT, int NL, bool EDGE>
+__global__ void __launch_bounds__(kBlock)
+exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+             const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ double sm_cs[2 * NJ * kBlock];
+  __shared__ unsigned short sm_list[kSegPrimMax * kPairCap * kBlock];
+  Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list};
+  const unsigned count = *A.queue_count;  // written by screen_kernel, the launch before on this stream
+  for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kBlock; base < count; base += static_cast<uint64_t>(gridDim.x) * kBlock) {
+    const uint64_t qi = base + threadIdx.x;
+    const bool mine = qi < count;
+    const uint64_t gi = A.queue[mine ? qi : (count - 1)];
+    double st[7 + NJ], Rw[9];
+    uint64_t edge;
+    int step;
+    fetch_state<NJ, EDGE, true>(A, gi, st, edge, step);
+    quat_to_mat(st[3], st[4], st[5], st[6], Rw);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      double sj, cj;
+      sincos_cw(st[7 + j], sj, cj);
+      sm.cs[(2 * j) * kBlock + threadIdx.x] = cj;
+      sm.cs[(2 * j + 1) * kBlock + threadIdx.x] = sj;
+    }
+    PROF_WAVE(15);
+    const bool hit = collide_exact<ROBOT, NL>(A, M, X, obs, obsf, st, Rw, sm, threadIdx.x, mine);
+    PROF_LANES(13, hit);
+    if (hit) {  // the screen wrote this state as valid-so-far
+      if (!EDGE) {
+        if (A.flags) A.flags[gi] = 0;
+        if (A.mask) atomicAnd(reinterpret_cast<unsigned long long*>(A.mask) + (gi >> 6), ~(1ull << (gi & 63)));
+      } else {
+        atomicMin(&A.first_invalid[edge], step);
+      }
+    }
+  }
+}
+
+template <int ROBOT, int NL>
+__global__ void __launch_bounds__(kBlock)
+full_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+            const DevObs* __restrict__ obs) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ double sm_cs[2 * NJ * kBlock];
+  __shared__ unsigned short sm_list[kListCap * kBlock];
+  Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list};
+
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, false, true>(A, li, st, edge, step);
+
+  StateOut o;
+  double thrust[NL];
+  double Rw[9];
+  bool finite;
+  model_update<ROBOT, NL, true>(A, M, X, st, sm, li, o, Rw, finite, thrust);
+
+  double mind = INFINITY;
+  if (A.do_coll && A.n_obs > 0 && __any(finite)) mind = collide_full<ROBOT, NL>(A, M, X, obs, st, Rw, sm, finite);
+  o.min_dist = (A.do_coll && finite) ? mind : INFINITY;
+  o.collision = A.do_coll && (mind <= 0.0);
+  o.valid = finite && (!A.do_stab || o.stable) && !o.collision;
+  o.band = !finite || (A.do_stab && fabs(o.margin) <= A.eps_margin) || (A.do_coll && fabs(o.min_dist) <= A.eps_dist);
+  if (!finite) { o.margin = -INFINITY; o.min_dist = NAN; o.stable = false; o.collision = false; }
+
+  if (in_range) {
+    if (A.flags) A.flags[gi] = o.valid ? 1 : 0;
+    if (A.band) A.band[gi] = o.band ? 1 : 0;
+    if (A.min_dist) A.min_dist[gi] = o.min_dist;
+    if (A.margin) A.margin[gi] = o.margin;
+    if (A.fc_t_min) A.fc_t_min[gi] = o.fc_t_min;
+    if (A.fc_rp_min) A.fc_rp_min[gi] = o.fc_rp_min;
+    if (A.rp_margin) A.rp_margin[gi] = o.rp_margin;
+    if (A.thrust) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) A.thrust[i * A.ld + gi] = thrust[i];
+    }
+  }
+  if (A.mask) {
+    const unsigned long long bal = __ballot(in_range && o.valid);
+    if ((threadIdx.x & 63) == 0 && (gi - (gi & 63)) < A.n) A.mask[gi >> 6] = bal;
   }
 
   // ---- per-block statistics (FULL batches): motion_planning.cpp:615-632 extrema ---
-  if (FULL && !EDGE && A.stats_partial) {
+  if (A.stats_partial) {
     __shared__ StatsPartial sm_part[kBlock / 64];
     StatsPartial mine;
     const long long idx = static_cast<long long>(gi);
@@ -1027,19 +1325,33 @@ template <int ROBOT, int NL>
 int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s) {
   const uint64_t blocks = (a.n + kBlock - 1) / kBlock;
   if (blocks == 0) return hipSuccess;
-  if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+  if (blocks > 0x7fffffffULL || a.n > 0xffffffffULL) return hipErrorInvalidValue;  // 32-bit queue entries
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+  if (a.full && !edge_mode) {
+    hipLaunchKernelGGL((full_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras, a.obs);
+    return hipGetLastError();
+  }
+  // exact stage: grid-stride over the queue; a few blocks per CU are enough to drain it
+  dim3 g2(static_cast<unsigned>(blocks < 1024 ? blocks : 1024));
   if (edge_mode) {
-    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, true>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
-  } else if (a.full) {
-    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, true, false>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
+    hipLaunchKernelGGL((screen_kernel<ROBOT, NL, true>), g, b, 0, s, a, a.model, a.extras, a.obsf);
+    if (a.do_coll && a.n_obs > 0) hipLaunchKernelGGL((exact_kernel<ROBOT, NL, true>), g2, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
   } else {
-    hipLaunchKernelGGL((validity_kernel<ROBOT, NL, false, false>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
+    hipLaunchKernelGGL((screen_kernel<ROBOT, NL, false>), g, b, 0, s, a, a.model, a.extras, a.obsf);
+    if (a.do_coll && a.n_obs > 0) hipLaunchKernelGGL((exact_kernel<ROBOT, NL, false>), g2, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
   }
   return hipGetLastError();
 }
 
 }  // namespace
+
+#ifdef MVK_PROF
+extern "C" int mvk_debug_prof(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 bool kernel_supported(int robot_type, int n_links) {
   if (robot_type == MVK_ROBOT_HYDRUS) return n_links == 4 || n_links == 6 || n_links == 8;

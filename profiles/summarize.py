@@ -11,11 +11,13 @@ print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
-print("== PMC (per dispatch averages for validity_kernel) ==")
+KERNELS = ("screen_kernel", "exact_kernel", "full_kernel", "validity_kernel")
+print("== PMC (per dispatch averages, per kernel) ==")
 for f in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
     acc = defaultdict(list)
     for row in csv.DictReader(open(f)):
-        if "validity_kernel" in row.get("Kernel_Name", ""):
-            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k, v in acc.items():
-        print(f"{k}: mean {sum(v)/len(v):.6g} over {len(v)} dispatches")
+        kn = next((k for k in KERNELS if k in row.get("Kernel_Name", "")), None)
+        if kn:
+            acc[(kn, row["Counter_Name"])].append(float(row["Counter_Value"]))
+    for (kn, k), v in sorted(acc.items()):
+        print(f"{kn} {k}: mean {sum(v)/len(v):.6g} over {len(v)} dispatches")
