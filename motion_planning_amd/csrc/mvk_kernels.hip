@@ -30,6 +30,9 @@ namespace {
 // scalar helpers
 // ------------------------------------------------------------------------
 #define DEV __device__ __forceinline__
+#ifndef MVK_RSQ_MASK
+#define MVK_RSQ_MASK 7
+#endif
 
 // Diagnostic builds only (profiles/diag.py, -DMVK_PROF): event counters, one atomic per wave.
 #ifdef MVK_PROF
@@ -78,6 +81,17 @@ DEV void sincos_cw(double x, double& s, double& c) {
   const double b = (q & 1) ? sr : cr;
   s = (q & 2) ? -a : a;
   c = ((q + 1) & 2) ? -b : b;
+}
+
+// 1/sqrt(x) for x > 0: hardware estimate + two Newton steps (relative error ~1e-16), without the
+// division and the square root of the IEEE sequence.  x = 0 / inf / NaN give non-finite results,
+// callers select around them.
+DEV double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = fma(y, fma(-hx * y, y, 0.5), y);
+  y = fma(y, fma(-hx * y, y, 0.5), y);
+  return y;
 }
 
 DEV double excess(double x, double h) {  // signed overshoot outside [-h, h]
@@ -256,6 +270,9 @@ struct Shape {
   static constexpr int axis(int k) { return kGimbal ? ((k & 1) ? 1 : 2) : 2; }
   static constexpr int joint(int k) { return k - 1; }
   static constexpr int rotor_seg(int i) { return kGimbal ? 2 * i : i; }
+  // waves per SIMD the screen kernel is compiled for (caps its VGPRs at 512 / waves): the walk-1
+  // arithmetic offers the scheduler more independent chains than pay off in registers
+  static constexpr int kScreenWaves = (!kGimbal && NL <= 4) ? 4 : 3;
 };
 
 constexpr int kListCap = 32;     // full path: per-lane narrowphase candidates per primitive
@@ -419,8 +436,13 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
       for (int k = 0; k < c; ++k) s = fma(-Lm[r][k], Lm[c][k], s);
       if (r == c) {
         singular = singular || !(s > 1e-14 * trace);
+#if MVK_RSQ_MASK & 1
+        Linv[r] = rsqrt_nr(s);
+        Lm[r][r] = s * Linv[r];
+#else
         Lm[r][r] = sqrt(s);
         Linv[r] = 1.0 / Lm[r][r];
+#endif
       } else {
         Lm[r][c] = s * Linv[c];
       }
@@ -462,8 +484,14 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
       const double nx = fma(V[i][1], V[j][2], -V[i][2] * V[j][1]);
       const double ny = fma(V[i][2], V[j][0], -V[i][0] * V[j][2]);
       const double nz = fma(V[i][0], V[j][1], -V[i][1] * V[j][0]);
-      const double nn = sqrt(fma(nx, nx, fma(ny, ny, nz * nz)));
+      const double n2 = fma(nx, nx, fma(ny, ny, nz * nz));
+#if MVK_RSQ_MASK & 2
+      const double rn = rsqrt_nr(n2);
+      const double sc = !(n2 * rn >= 1e-5) ? 0.0 : fmaxT * rn;  // |n| < 1e-5 (n2 = 0 gives NaN): distance 0
+#else
+      const double nn = sqrt(n2);
       const double sc = (nn < 1e-5) ? 0.0 : fmaxT / nn;
+#endif
       double dp = 0.0, dm = 0.0;
 #pragma unroll
       for (int k = 0; k < NL; ++k) {
@@ -473,13 +501,26 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
         dm += fmax(-tp, 0.0);
       }
       fc_t = fmin(fc_t, fmin(dp, dm));
+      // the pairs are independent: without a fence the scheduler interleaves all of them and
+      // the live ranges cost a wave of occupancy
+#ifdef MVK_SCHED_FENCE
+  #ifdef MVK_SCHED_FENCE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
     }
   // roll/pitch version
   double fc_rp = INFINITY;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    const double na = sqrt(fma(V[i][0], V[i][0], V[i][1] * V[i][1]));
+    const double na2 = fma(V[i][0], V[i][0], V[i][1] * V[i][1]);
+#if MVK_RSQ_MASK & 4
+    const double ra = rsqrt_nr(na2);
+    const double sc = !(na2 * ra >= 1e-5) ? 0.0 : fmaxT * ra;
+#else
+    const double na = sqrt(na2);
     const double sc = (na < 1e-5) ? 0.0 : fmaxT / na;
+#endif
     double d = 0.0;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
@@ -487,6 +528,9 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
       d += fmax(fma(V[i][1], V[j][0], -V[i][0] * V[j][1]) * sc, 0.0);
     }
     fc_rp = fmin(fc_rp, d);
+#ifdef MVK_SCHED_FENCE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
   out.fc_t_min = fc_t;
   out.fc_rp_min = fc_rp;
@@ -1061,7 +1105,7 @@ DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t
 //                   (or lowers first_invalid of its edge).
 // Full path = full_kernel: exact minimum distance, margins, details and statistics, no early exit.
 template <int ROBOT, int NL, bool EDGE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, (Shape<ROBOT, NL>::kScreenWaves))
 screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
               const DevObsF* __restrict__ obsf) {
   using S = Shape<ROBOT, NL>;
