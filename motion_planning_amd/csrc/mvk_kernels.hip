@@ -774,6 +774,7 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
 #pragma unroll
         for (int c = 0; c < kGridGroup; ++c) {
           const bool real = ids[c] != kGridNone;
+          if (c > 0 && !__any(real)) break;  // lists are padded at the end only
 #pragma unroll
           for (int j = 0; j < kSegPrimMax; ++j) {
             if (j < np) {
