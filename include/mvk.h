@@ -229,6 +229,13 @@ void mvk_destroy(mvk_ctx* ctx);
 int mvk_set_scene(mvk_ctx* ctx, const mvk_box* boxes, size_t n_boxes);
 int mvk_set_params(mvk_ctx* ctx, const mvk_params* params);
 int mvk_get_params(const mvk_ctx* ctx, mvk_params* out);
+/* Kernel timing for benchmarks (no counterpart in the reference, which only times the whole
+ * solve: motion_planning.cpp:406-410).  When enabled, every batched call records HIP events on
+ * its launch stream around its kernels; mvk_last_kernel_ms waits for the last call and returns
+ * the duration of its first kernel (the screen kernel of the flag path, or the full-evaluation
+ * kernel) and of its second kernel (the exact stage of the flag path; 0 when there is none). */
+int mvk_set_profiling(mvk_ctx* ctx, int enable);
+int mvk_last_kernel_ms(mvk_ctx* ctx, float* first_ms, float* second_ms);
 /* rows of a state in the given layout for the ctx's (mode, motion type) */
 int mvk_state_dim(const mvk_ctx* ctx, int layout);
 

@@ -119,6 +119,8 @@ PROTOTYPES = {
     "mvk_set_scene": (ip, [vp, PB, sz]),
     "mvk_set_params": (ip, [vp, PP]),
     "mvk_get_params": (ip, [vp, PP]),
+    "mvk_set_profiling": (ip, [vp, ip]),
+    "mvk_last_kernel_ms": (ip, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mvk_state_dim": (ip, [vp, ip]),
     "mvk_is_valid": (ip, [vp, vp, C.POINTER(Result)]),
     "mvk_is_valid_batch": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp]),

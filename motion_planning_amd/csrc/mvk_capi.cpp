@@ -83,6 +83,9 @@ struct mvk_ctx {
   // Calls on one ctx must therefore be ordered with respect to each other (one stream at a time).
   Buf queue, queue_counts;
   uint64_t call_index = 0;
+  // optional kernel timing (mvk_set_profiling): events around the kernels of the last call
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  bool profiling = false, timed = false;
   GridDev grid{};
   int n_obs = 0;
   float f32_delta = 0.0f;
@@ -342,7 +345,8 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
   } else if (int rc = prepare_queue(c, a, n)) {
     return rc;
   }
-  const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s);
+  const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s, c->profiling ? c->ev : nullptr);
+  c->timed = c->profiling;
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
   c->stats_valid = a.full != 0;
   return MVK_OK;
@@ -459,6 +463,8 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
   }
+  for (hipEvent_t& e : c->ev)
+    if (e) (void)hipEventDestroy(e);
   if (c->d_model) (void)hipFree(c->d_model);
   if (c->d_extras) (void)hipFree(c->d_extras);
   Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->queue, &c->queue_counts, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
@@ -485,6 +491,27 @@ extern "C" int mvk_set_params(mvk_ctx* c, const mvk_params* p) {
 extern "C" int mvk_get_params(const mvk_ctx* c, mvk_params* out) {
   if (!c || !out) return fail(MVK_ERR_INVALID_ARG, "null argument");
   *out = c->params;
+  return MVK_OK;
+}
+
+extern "C" int mvk_set_profiling(mvk_ctx* c, int enable) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  HIP_TRY(hipSetDevice(c->device));
+  if (enable)
+    for (hipEvent_t& e : c->ev)
+      if (!e) HIP_TRY(hipEventCreate(&e));
+  c->profiling = enable != 0;
+  c->timed = false;
+  return MVK_OK;
+}
+
+extern "C" int mvk_last_kernel_ms(mvk_ctx* c, float* first_ms, float* second_ms) {
+  if (!c || !first_ms || !second_ms) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  if (!c->timed) return fail(MVK_ERR_INVALID_ARG, "mvk_last_kernel_ms: no timed call (enable mvk_set_profiling first)");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventSynchronize(c->ev[2]));
+  HIP_TRY(hipEventElapsedTime(first_ms, c->ev[0], c->ev[1]));
+  HIP_TRY(hipEventElapsedTime(second_ms, c->ev[1], c->ev[2]));
   return MVK_OK;
 }
 
@@ -638,7 +665,8 @@ int run_edges_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_e
   c->stats_valid = false;
   if (int rc = prepare_queue(c, a, total)) return rc;
   int e = launch_edge_init(d_first, d_nd, a.nd_uniform, n_edges, s);
-  if (e == hipSuccess) e = launch_eval(a, c->model.robot_type, c->model.n_rotor, true, s);
+  if (e == hipSuccess) e = launch_eval(a, c->model.robot_type, c->model.n_rotor, true, s, c->profiling ? c->ev : nullptr);
+  c->timed = c->profiling;
   if (e == hipSuccess && d_ok) e = launch_edge_finish(d_first, d_nd, a.nd_uniform, d_ok, n_edges, s);
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "edge kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
   return MVK_OK;

@@ -127,7 +127,8 @@ constexpr int kBlock = 256;
 constexpr int kSegPrimMax = 3;  // collision primitives riding on one segment (checked by mvk_create)
 
 // launchers implemented in mvk_kernels.hip; return hipError_t as int
-int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream);
+// events: nullptr, or hipEvent_t[3] recorded before / between / after the kernels of the call
+int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream, void* events);
 int launch_edge_init(int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint64_t n_edges, void* stream);
 int launch_edge_finish(const int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint8_t* ok,
                        uint64_t n_edges, void* stream);

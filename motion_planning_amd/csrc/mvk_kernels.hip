@@ -1366,25 +1366,32 @@ __global__ void stats_final_kernel(const StatsPartial* part, uint64_t n, StatsPa
   }
 }
 
+// ev (nullable): three events recorded on the launch stream around the kernels
+// (before the first, between first and second, after the last) for mvk_last_kernel_ms
 template <int ROBOT, int NL>
-int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s) {
+int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s, hipEvent_t* ev) {
   const uint64_t blocks = (a.n + kBlock - 1) / kBlock;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffULL || a.n > 0xffffffffULL) return hipErrorInvalidValue;  // 32-bit queue entries
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+  if (ev) (void)hipEventRecord(ev[0], s);
   if (a.full && !edge_mode) {
     hipLaunchKernelGGL((full_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras, a.obs);
+    if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
     return hipGetLastError();
   }
   // exact stage: grid-stride over the queue; a few blocks per CU are enough to drain it
   dim3 g2(static_cast<unsigned>(blocks < 1024 ? blocks : 1024));
   if (edge_mode) {
     hipLaunchKernelGGL((screen_kernel<ROBOT, NL, true>), g, b, 0, s, a, a.model, a.extras, a.obsf);
+    if (ev) (void)hipEventRecord(ev[1], s);
     if (a.do_coll && a.n_obs > 0) hipLaunchKernelGGL((exact_kernel<ROBOT, NL, true>), g2, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
   } else {
     hipLaunchKernelGGL((screen_kernel<ROBOT, NL, false>), g, b, 0, s, a, a.model, a.extras, a.obsf);
+    if (ev) (void)hipEventRecord(ev[1], s);
     if (a.do_coll && a.n_obs > 0) hipLaunchKernelGGL((exact_kernel<ROBOT, NL, false>), g2, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
   }
+  if (ev) (void)hipEventRecord(ev[2], s);
   return hipGetLastError();
 }
 
@@ -1404,17 +1411,18 @@ bool kernel_supported(int robot_type, int n_links) {
   return false;
 }
 
-int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream) {
+int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream, void* events) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t* ev = static_cast<hipEvent_t*>(events);
   if (robot_type == MVK_ROBOT_HYDRUS) {
     switch (n_links) {
-      case 4: return launch_shape<MVK_ROBOT_HYDRUS, 4>(a, edge_mode, s);
-      case 6: return launch_shape<MVK_ROBOT_HYDRUS, 6>(a, edge_mode, s);
-      case 8: return launch_shape<MVK_ROBOT_HYDRUS, 8>(a, edge_mode, s);
+      case 4: return launch_shape<MVK_ROBOT_HYDRUS, 4>(a, edge_mode, s, ev);
+      case 6: return launch_shape<MVK_ROBOT_HYDRUS, 6>(a, edge_mode, s, ev);
+      case 8: return launch_shape<MVK_ROBOT_HYDRUS, 8>(a, edge_mode, s, ev);
       default: break;
     }
   } else if (robot_type == MVK_ROBOT_DRAGON) {
-    if (n_links == 4) return launch_shape<MVK_ROBOT_DRAGON, 4>(a, edge_mode, s);
+    if (n_links == 4) return launch_shape<MVK_ROBOT_DRAGON, 4>(a, edge_mode, s, ev);
   }
   return hipErrorInvalidValue;
 }

@@ -159,6 +159,15 @@ class Engine:
         _check(self.lib, self.lib.mvk_set_params(self.ctx, C.byref(params)))
         self.params = params
 
+    def set_profiling(self, enable=True):
+        _check(self.lib, self.lib.mvk_set_profiling(self.ctx, int(enable)))
+
+    def last_kernel_ms(self):
+        """(first kernel ms, second kernel ms) of the last batched call; needs set_profiling(True)."""
+        a, b = C.c_float(), C.c_float()
+        _check(self.lib, self.lib.mvk_last_kernel_ms(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def state_dim(self, layout):
         return self.lib.mvk_state_dim(self.ctx, layout)
 

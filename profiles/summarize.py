@@ -1,23 +1,58 @@
 #!/usr/bin/env python3
-"""Condenses rocprofv3 csv output (kernel stats + PMC passes) into a short text summary."""
+"""Condenses rocprofv3 csv output (kernel stats + PMC passes) into a short text summary.
+
+usage: summarize.py <profile dir> [--merge profiles/latest_pmc.json --workload c2 --source <name>]
+With --merge, the per-launch HBM traffic and VALU utilisation of the dominant kernel (screen_kernel) are
+written into the json that bench.py reads for its roofline object:
+  hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (FETCH_SIZE doubled: gfx950 reports half of a
+                          wide streaming read, MI355X_MICROARCH.md "HBM"; both counters are in KiB)
+  valu_busy            = 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 * 1024)
+                         (quad-cycles summed over the chip vs cycles of one XCD times the 1024 SIMDs)
+"""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
-out = sys.argv[1]
-print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
-for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
 KERNELS = ("screen_kernel", "exact_kernel", "full_kernel", "validity_kernel")
-print("== PMC (per dispatch averages, per kernel) ==")
-for f in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
-    acc = defaultdict(list)
-    for row in csv.DictReader(open(f)):
-        kn = next((k for k in KERNELS if k in row.get("Kernel_Name", "")), None)
-        if kn:
-            acc[(kn, row["Counter_Name"])].append(float(row["Counter_Value"]))
-    for (kn, k), v in sorted(acc.items()):
-        print(f"{kn} {k}: mean {sum(v)/len(v):.6g} over {len(v)} dispatches")
+
+
+def main():
+    out = sys.argv[1]
+    args = sys.argv[2:]
+    opt = {args[i][2:]: args[i + 1] for i in range(0, len(args) - 1, 2) if args[i].startswith("--")}
+    print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+    print("== PMC (per dispatch averages, per kernel) ==")
+    mean = {}
+    for f in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+        acc = defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            kn = next((k for k in KERNELS if k in row.get("Kernel_Name", "")), None)
+            if kn:
+                acc[(kn, row["Counter_Name"])].append(float(row["Counter_Value"]))
+        for (kn, k), v in sorted(acc.items()):
+            mean[(kn, k)] = sum(v) / len(v)
+            print(f"{kn} {k}: mean {sum(v)/len(v):.6g} over {len(v)} dispatches")
+    kn = "screen_kernel"
+    if (kn, "FETCH_SIZE") in mean and (kn, "GRBM_GUI_ACTIVE") in mean:
+        hbm = (2.0 * mean[(kn, "FETCH_SIZE")] + mean.get((kn, "WRITE_SIZE"), 0.0)) * 1024.0
+        busy = 4.0 * mean[(kn, "SQ_ACTIVE_INST_VALU")] / (mean[(kn, "GRBM_GUI_ACTIVE")] / 8.0 * 1024.0)
+        print(f"== derived ({kn}) ==\nhbm_bytes_per_launch {hbm:.6g}\nvalu_busy {busy:.4f}\n"
+              f"valu_insts_per_wave {mean[(kn, 'SQ_INSTS_VALU')] / mean[(kn, 'SQ_WAVES')]:.1f}")
+        if "merge" in opt:
+            try:
+                d = json.load(open(opt["merge"]))
+            except (OSError, ValueError):
+                d = {}
+            d[opt.get("workload", "c2")] = {"kernel": kn, "hbm_bytes_per_launch": hbm, "valu_busy": busy,
+                                           "source": opt.get("source", os.path.basename(out.rstrip("/")))}
+            json.dump(d, open(opt["merge"], "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
