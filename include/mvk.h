@@ -268,6 +268,38 @@ int mvk_eval_batch_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, i
 /* extrema over the last *_batch / eval call on this ctx (device reduction) */
 int mvk_reduce_stats(mvk_ctx* ctx, mvk_stats* out);
 
+/* ---- collision-avoidance constraint rows --------------------- *
+ * differential_kinematics CollisionAvoidance::getConstraint
+ * (differential_kinematics/src/constraint/collision_avoidance.cpp:102-277) for a batch of
+ * states: per robot collision primitive q (model order) the minimum distance to the world
+ * boxes with nearest points (:147-153), the closest box, the row  n^T J_lin  (:255-260) over
+ * the columns [root linear velocity (world), root angular velocity (world), planned joints
+ * j1..jJ], and the lower bound damplingBound(dist, -gain, range, forbidden) (:262-265,
+ * constraint/base_plugin.h:108-113; -1e6 = unconstrained).  ok[i] = 0 where getConstraint
+ * would fail because a distance is <= 0 (:214-218); such primitives get NaN points and a
+ * zero row.  Gimbal angles count as fixed.  Every output pointer may be NULL. */
+typedef struct mvk_avoid_params {
+  double damping_gain;     /* collision_damping_gain, default 0.01 (:68) */
+  double constraint_range; /* collision_distance_constraint_range, default 0.03 (:69) */
+  double forbidden_range;  /* collision_distance_forbidden_range, default 0.01 (:70) */
+  int32_t full_body;       /* 0: the six root columns are zeroed (:267) */
+} mvk_avoid_params;
+typedef struct mvk_avoid_out {
+  double* dist;    /* [n_prim][ld] */
+  int32_t* box;    /* [n_prim][ld]  index of the closest box, -1 in an empty world */
+  double* p_env;   /* [3*n_prim][ld]  nearest point on the environment, world frame */
+  double* p_robot; /* [3*n_prim][ld]  nearest point on the robot primitive, world frame */
+  double* row;     /* [(6+J)*n_prim][ld] */
+  double* lb;      /* [n_prim][ld] */
+  uint8_t* ok;     /* [ld] */
+} mvk_avoid_out;
+int mvk_avoid_params_default(mvk_avoid_params* out);
+int mvk_collision_avoidance_batch(mvk_ctx* ctx, const double* soa, size_t n, size_t ld, int layout,
+                                  const mvk_avoid_params* prm, const mvk_avoid_out* out);
+/* device pointers; output rows use the same pitch ld as the states */
+int mvk_collision_avoidance_batch_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout,
+                                      const mvk_avoid_params* prm, const mvk_avoid_out* d_out, void* stream);
+
 /* ---- motion validation ------------------------------------------------------- */
 /* ompl::base::DiscreteMotionValidator::checkMotion bound at
  * motion_planning.cpp:238,249 (and the densification loop :434-444).

@@ -63,6 +63,14 @@ class DetailOut(C.Structure):
                 ("rp_position_margin", C.c_void_p), ("cog", C.c_void_p), ("gimbal", C.c_void_p)]
 
 
+class AvoidParams(C.Structure):
+    _fields_ = [("damping_gain", d), ("constraint_range", d), ("forbidden_range", d), ("full_body", i32)]
+
+
+class AvoidOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("dist", "box", "p_env", "p_robot", "row", "lb", "ok")]
+
+
 class Stats(C.Structure):
     _fields_ = [("n", C.c_uint64), ("valid_count", C.c_uint64), ("band_count", C.c_uint64),
                 ("min_dist", d), ("min_dist_index", C.c_int64),
@@ -129,6 +137,9 @@ PROTOTYPES = {
     "mvk_eval_batch": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, C.POINTER(DetailOut)]),
     "mvk_eval_batch_dev": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, C.POINTER(DetailOut), vp]),
     "mvk_reduce_stats": (ip, [vp, C.POINTER(Stats)]),
+    "mvk_avoid_params_default": (ip, [C.POINTER(AvoidParams)]),
+    "mvk_collision_avoidance_batch": (ip, [vp, vp, sz, sz, ip, C.POINTER(AvoidParams), C.POINTER(AvoidOut)]),
+    "mvk_collision_avoidance_batch_dev": (ip, [vp, vp, sz, sz, ip, C.POINTER(AvoidParams), C.POINTER(AvoidOut), vp]),
     "mvk_check_motion_batch": (ip, [vp, vp, vp, sz, sz, vp, i32, vp, vp]),
     "mvk_check_motion_batch_dev": (ip, [vp, vp, vp, sz, sz, vp, i32, vp, vp, vp]),
     "mvk_space_dim": (ip, [PP, ip]),

@@ -92,7 +92,7 @@ struct mvk_ctx {
   double f32_range = 0.0;
   hipStream_t stream = nullptr;
   // staging for the host-pointer entry points
-  Buf in_a, in_b, flags, band, mind, margin, det[6], nd, ok, first, edge_off;
+  Buf in_a, in_b, flags, band, mind, margin, det[6], nd, ok, first, edge_off, av[7];
   // statistics of the last FULL batch
   Buf partial, stats_out;
   uint64_t last_blocks = 0, last_n = 0;
@@ -469,7 +469,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
   if (c->d_extras) (void)hipFree(c->d_extras);
   Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->queue, &c->queue_counts, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
-                &c->partial, &c->stats_out};
+                &c->partial, &c->stats_out, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
   for (Buf* b : all) b->release();
   delete c;
 }
@@ -641,6 +641,75 @@ extern "C" int mvk_reduce_stats(mvk_ctx* c, mvk_stats* out) {
   out->max_thrust = h.max_thrust; out->max_thrust_index = h.max_thrust_index;
   out->min_thrust = h.min_thrust; out->min_thrust_index = h.min_thrust_index;
   out->min_rp_position_margin = h.min_rp; out->min_rp_position_margin_index = h.min_rp_index;
+  return MVK_OK;
+}
+
+// ---- collision-avoidance constraint rows ------------------------------------------
+extern "C" int mvk_avoid_params_default(mvk_avoid_params* p) {
+  if (!p) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  p->damping_gain = 0.01;      // collision_avoidance.cpp:68
+  p->constraint_range = 0.03;  // :69
+  p->forbidden_range = 0.01;   // :70
+  p->full_body = 1;
+  return MVK_OK;
+}
+
+extern "C" int mvk_collision_avoidance_batch_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout,
+                                                 const mvk_avoid_params* prm, const mvk_avoid_out* o, void* stream) {
+  if (!c || !prm || !o) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  if (n == 0) return MVK_OK;
+  if (!d_soa || ld < n) return fail(MVK_ERR_INVALID_ARG, "bad state array (null, or ld < n)");
+  if (!(prm->constraint_range > prm->forbidden_range)) return fail(MVK_ERR_INVALID_ARG, "constraint_range must exceed forbidden_range");
+  const int rows = layout_rows(c, layout);
+  if (rows < 0) return rows;
+  HIP_TRY(hipSetDevice(c->device));
+  EvalArgs a;
+  base_args(c, a);
+  a.soa = d_soa;
+  a.n = n;
+  a.ld = ld;
+  a.layout = layout;
+  a.av_gain = prm->damping_gain;
+  a.av_range = prm->constraint_range;
+  a.av_forbid = prm->forbidden_range;
+  a.av_full_body = prm->full_body;
+  a.av_dist = o->dist; a.av_box = o->box; a.av_p_env = o->p_env; a.av_p_robot = o->p_robot;
+  a.av_row = o->row; a.av_lb = o->lb; a.av_ok = o->ok;
+  c->stats_valid = false;
+  const int e = launch_avoid(a, c->model.robot_type, c->model.n_rotor, stream);
+  if (e != hipSuccess) return fail(MVK_ERR_HIP, "avoidance kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+  return MVK_OK;
+}
+
+extern "C" int mvk_collision_avoidance_batch(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout,
+                                             const mvk_avoid_params* prm, const mvk_avoid_out* o) {
+  if (!c || !prm || !o) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  if (n == 0) return MVK_OK;
+  if (!soa || ld < n) return fail(MVK_ERR_INVALID_ARG, "bad state array (null, or ld < n)");
+  const int rows = layout_rows(c, layout);
+  if (rows < 0) return rows;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t dld = round_up(n, 64), P = static_cast<size_t>(c->model.n_prim), W = 6 + static_cast<size_t>(c->model.n_joint);
+  if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
+  if (int rc = copy_rows(c->in_a.p, dld, soa, ld, sizeof(double), n, rows, hipMemcpyHostToDevice, s)) return rc;
+  void* host[7] = {o->dist, o->box, o->p_env, o->p_robot, o->row, o->lb, o->ok};
+  const size_t nrows[7] = {P, P, 3 * P, 3 * P, W * P, P, 1};
+  const size_t elem[7] = {8, 4, 8, 8, 8, 8, 1};
+  void* dev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < 7; ++k)
+    if (host[k]) {
+      if (int rc = c->av[k].reserve(dld * nrows[k] * elem[k])) return rc;
+      dev[k] = c->av[k].p;
+    }
+  mvk_avoid_out d{static_cast<double*>(dev[0]), static_cast<int32_t*>(dev[1]), static_cast<double*>(dev[2]),
+                  static_cast<double*>(dev[3]), static_cast<double*>(dev[4]), static_cast<double*>(dev[5]),
+                  static_cast<uint8_t*>(dev[6])};
+  if (int rc = mvk_collision_avoidance_batch_dev(c, static_cast<const double*>(c->in_a.p), n, dld, layout, prm, &d, s)) return rc;
+  for (int k = 0; k < 7; ++k)
+    if (host[k])
+      if (int rc = copy_rows(host[k], ld, dev[k], dld, elem[k], n, nrows[k], hipMemcpyDeviceToHost, s)) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
   return MVK_OK;
 }
 

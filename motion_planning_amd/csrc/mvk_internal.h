@@ -112,6 +112,16 @@ struct EvalArgs {
   uint32_t* queue_count_next;  // zeroed by this call for the next one
   // per-block partial statistics (full mode) or nullptr
   void* stats_partial;
+  // collision-avoidance rows (avoid_kernel): parameters and nullable outputs, row pitch ld
+  double av_gain, av_range, av_forbid;
+  int32_t av_full_body;
+  double* av_dist;     // [P][ld]
+  int32_t* av_box;     // [P][ld]
+  double* av_p_env;    // [3P][ld]
+  double* av_p_robot;  // [3P][ld]
+  double* av_row;      // [(6+J)P][ld]
+  double* av_lb;       // [P][ld]
+  uint8_t* av_ok;      // [ld]
 };
 
 struct StatsPartial {
@@ -129,6 +139,7 @@ constexpr int kSegPrimMax = 3;  // collision primitives riding on one segment (c
 // launchers implemented in mvk_kernels.hip; return hipError_t as int
 // events: nullptr, or hipEvent_t[3] recorded before / between / after the kernels of the call
 int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream, void* events);
+int launch_avoid(const EvalArgs& a, int robot_type, int n_links, void* stream);
 int launch_edge_init(int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint64_t n_edges, void* stream);
 int launch_edge_finish(const int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint8_t* ok,
                        uint64_t n_edges, void* stream);

@@ -252,6 +252,75 @@ DEV double box_edges_to_box2(const double c[3], const double R[9], const double 
   return best;
 }
 
+
+// ---- closest points (collision-avoidance rows) -----------------
+// as seg_box_dist2, also returning the point on the segment (y) and on the box (z), box frame
+DEV double seg_box_closest2(const double p0[3], const double d[3], const double h[3], double y[3], double z[3]) {
+  const double g0 = seg_grad(p0, d, h, 0.0), g1 = seg_grad(p0, d, h, 1.0);
+  double tlo = 0.0, glo = g0, thi = 1.0, ghi = g1;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double inv = 1.0 / d[k];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const double t = ((sg ? -h[k] : h[k]) - p0[k]) * inv;
+      if (t > 0.0 && t < 1.0) {  // false for NaN / inf (d[k] == 0)
+        const double g = seg_grad(p0, d, h, t);
+        if (g < 0.0) {
+          if (t > tlo) { tlo = t; glo = g; }
+        } else if (t < thi) { thi = t; ghi = g; }
+      }
+    }
+  }
+  double ts = (ghi > glo) ? fma(thi - tlo, -glo / (ghi - glo), tlo) : tlo;
+  ts = (g1 <= 0.0) ? 1.0 : ts;
+  ts = (g0 >= 0.0) ? 0.0 : ts;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    y[k] = fma(ts, d[k], p0[k]);
+    z[k] = fmin(fmax(y[k], -h[k]), h[k]);
+    const double e = y[k] - z[k];
+    s = fma(e, e, s);
+  }
+  return s;
+}
+
+// closest pair between the 12 edges of box A (in B's frame) and solid B: squared distance,
+// pa on A's edge, pb on B (both in B's frame)
+DEV double box_edges_to_box_cp2(const double c[3], const double R[9], const double a[3], const double b[3],
+                                double pa[3], double pb[3]) {
+  double best = INFINITY;
+#pragma unroll 1
+  for (int e = 0; e < 12; ++e) {
+    // same edge order as the oracle: axis, then the sign of u, then the sign of v
+    const int ax = e >> 2;
+    const double su = (e & 2) ? 1.0 : -1.0, sv = (e & 1) ? 1.0 : -1.0;
+    double p0[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double cx = R[3 * k], cy = R[3 * k + 1], cz = R[3 * k + 2];
+      const double Aax = ax == 0 ? cx : (ax == 1 ? cy : cz);
+      const double Au = ax == 0 ? cy : (ax == 1 ? cz : cx);
+      const double Av = ax == 0 ? cz : (ax == 1 ? cx : cy);
+      const double hax = ax == 0 ? a[0] : (ax == 1 ? a[1] : a[2]);
+      const double hu = ax == 0 ? a[1] : (ax == 1 ? a[2] : a[0]);
+      const double hv = ax == 0 ? a[2] : (ax == 1 ? a[0] : a[1]);
+      const double mid = fma(su * hu, Au, fma(sv * hv, Av, c[k]));
+      p0[k] = fma(-hax, Aax, mid);
+      d[k] = 2.0 * hax * Aax;
+    }
+    double y[3], z[3];
+    const double s2 = seg_box_closest2(p0, d, b, y, z);
+    if (s2 < best) {
+      best = s2;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { pa[k] = y[k]; pb[k] = z[k]; }
+    }
+  }
+  return best;
+}
+
 // ------------------------------------------------------------------------
 // per-state evaluation
 // ------------------------------------------------------------------------
@@ -966,6 +1035,60 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
   return mind;
 }
 
+
+// signed distance of one primitive to one box with the nearest points (box frame): pr on the robot
+// primitive, pe on the box.  Points are NaN when the pair is in contact (distance <= 0).
+DEV double narrow_cp(int type, const double PR[9], double d0, double d1, double d2, const DevObs& O, const double t[3],
+                     double pr[3], double pe[3]) {
+  pr[0] = pr[1] = pr[2] = pe[0] = pe[1] = pe[2] = NAN;
+  if (type != MVK_PRIM_BOX) {
+    const double hl = type == MVK_PRIM_CAPSULE ? d1 : 0.0;
+    double a[3], p0[3], dd[3], y[3], z[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[c] = fma(O.R[c], PR[2], fma(O.R[3 + c], PR[5], O.R[6 + c] * PR[8]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { p0[c] = fma(-hl, a[c], t[c]); dd[c] = 2.0 * hl * a[c]; }
+    const double core = sqrt(seg_box_closest2(p0, dd, O.h, y, z));
+    const double d = core - d0;
+    if (d > 0.0) {
+      const double sc = d0 / core;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { pe[c] = z[c]; pr[c] = fma(sc, z[c] - y[c], y[c]); }
+    }
+    return d;
+  }
+  double Rr[9];  // primitive axes in the box frame
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      Rr[3 * r + c] = fma(O.R[r], PR[c], fma(O.R[3 + r], PR[3 + c], O.R[6 + r] * PR[6 + c]));
+  const double a[3] = {d0, d1, d2};
+  double d = box_box_sat<true>(t, Rr, a, O.h);
+  if (!(d > 0.0)) return d;
+  double pa1[3], pb1[3], pa2[3], pb2[3];
+  const double s1 = box_edges_to_box_cp2(t, Rr, a, O.h, pa1, pb1);  // pa1 on the robot, pb1 on the box
+  double Rt[9], tb[3];  // the box in the primitive's frame
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Rt[3 * r + c] = Rr[3 * c + r];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) tb[r] = -fma(Rr[r], t[0], fma(Rr[3 + r], t[1], Rr[6 + r] * t[2]));
+  const double s2 = box_edges_to_box_cp2(tb, Rt, O.h, a, pa2, pb2);  // pa2 on the box, pb2 on the robot (primitive frame)
+  if (s1 <= s2) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pr[c] = pa1[c]; pe[c] = pb1[c]; }
+    return sqrt(s1);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {  // primitive frame -> box frame: x_B = Rr x_A + t
+    pe[c] = fma(Rr[3 * c], pa2[0], fma(Rr[3 * c + 1], pa2[1], fma(Rr[3 * c + 2], pa2[2], t[c])));
+    pr[c] = fma(Rr[3 * c], pb2[0], fma(Rr[3 * c + 1], pb2[1], fma(Rr[3 * c + 2], pb2[2], t[c])));
+  }
+  return sqrt(s2);
+}
+
 // ------------------------------------------------------------------------
 // state fetch: SoA batch rows, or in-kernel edge densification
 // ------------------------------------------------------------------------
@@ -1318,6 +1441,157 @@ full_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* 
   }
 }
 
+
+// Collision-avoidance constraint rows: differential_kinematics CollisionAvoidance::getConstraint
+// (src/constraint/collision_avoidance.cpp:102-277) for a batch of states.  One lane per state;
+// per collision primitive the minimum distance over the world boxes with nearest points (:147-153),
+// the normal from the environment to the robot (:255), the row n^T J_lin over
+// [root v (world), root w (world), planned joints] (:259-260) and the damped bound (:262-265).
+template <int ROBOT, int NL>
+__global__ void __launch_bounds__(kBlock)
+avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+             const DevObs* __restrict__ obs) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint, W = 6 + NJ;
+  __shared__ double sm_cs[2 * NJ * kBlock];
+  __shared__ unsigned short sm_list[kListCap * kBlock];
+  Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list};
+  const int tid = threadIdx.x;
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + tid;
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, false, true>(A, li, st, edge, step);
+  double Rw[9];
+  quat_to_mat(st[3], st[4], st[5], st[6], Rw);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    double sj, cj;
+    sincos_cw(st[7 + j], sj, cj);
+    sm.cs[(2 * j) * kBlock + tid] = cj;
+    sm.cs[(2 * j + 1) * kBlock + tid] = sj;
+  }
+  double R[9], p[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = Rw[k];
+  p[0] = st[0]; p[1] = st[1]; p[2] = st[2];
+  bool ok = true;
+#pragma unroll 1
+  for (int k = 0; k < S::kSeg; ++k) {
+    if (k > 0) advance_frame(M, sm, tid, k, R, p);
+    const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
+#pragma unroll 1
+    for (int qi = pb; qi < pe; ++qi) {
+      const int q = X->prim_order[qi];
+      const int type = M->prim_type[q];
+      double pc[3], PR[9];
+      prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
+      const double rb = X->prim_bound[q];
+      const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+      auto centre_dist2 = [&](const DevObs& O) {
+        double t[3];
+        to_box_frame(O, pc, t);
+        return point_box_dist2(t, O.h);
+      };
+      // the primitive's origin lies inside it: the nearest box to the origin bounds the separation from above
+      double best2 = INFINITY;
+#pragma unroll 2
+      for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
+      const double thr = rb + sqrt(best2);
+      const double thr2 = thr * thr * (1.0 + 1e-12);
+      int cnt = 0;
+#pragma unroll 2
+      for (int ob = 0; ob < A.n_obs; ++ob) {
+        if (centre_dist2(obs[ob]) <= thr2) {
+          if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
+          ++cnt;
+        }
+      }
+      const bool overflow = cnt > kListCap;
+      const int todo = overflow ? A.n_obs : cnt;
+      double best = INFINITY, br[3] = {NAN, NAN, NAN}, be[3] = {NAN, NAN, NAN};
+      int bi = -1;
+#pragma unroll 1
+      for (int e = 0; __any(e < todo); ++e) {
+        if (e < todo) {
+          const int ob = overflow ? e : sm.list[e * kBlock + tid];
+          const DevObs O = obs[ob];
+          double t[3], pr[3], pq[3];
+          to_box_frame(O, pc, t);
+          const double d = narrow_cp(type, PR, d0, d1, d2, O, t, pr, pq);
+          if (d < best) {  // ascending box order, strict: the first minimum wins, as in the oracle
+            best = d;
+            bi = ob;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {  // box frame -> world
+              br[c] = fma(O.R[3 * c], pr[0], fma(O.R[3 * c + 1], pr[1], fma(O.R[3 * c + 2], pr[2], O.c[c])));
+              be[c] = fma(O.R[3 * c], pq[0], fma(O.R[3 * c + 1], pq[1], fma(O.R[3 * c + 2], pq[2], O.c[c])));
+            }
+          }
+        }
+      }
+      const bool usable = bi >= 0 && best > 0.0;
+      ok = ok && (bi < 0 || best > 0.0);
+      // normal from the environment to the robot, and the row over the chain up to this segment
+      double nrm[3] = {br[0] - be[0], br[1] - be[1], br[2] - be[2]};
+      const double inv = 1.0 / sqrt(fma(nrm[0], nrm[0], fma(nrm[1], nrm[1], nrm[2] * nrm[2])));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nrm[c] = usable ? nrm[c] * inv : 0.0;
+      double row[W];
+#pragma unroll
+      for (int c = 0; c < W; ++c) row[c] = 0.0;
+      if (A.av_full_body) {
+        const double rx = br[0] - st[0], ry = br[1] - st[1], rz = br[2] - st[2];
+        row[0] = nrm[0]; row[1] = nrm[1]; row[2] = nrm[2];
+        row[3] = usable ? fma(ry, nrm[2], -rz * nrm[1]) : 0.0;
+        row[4] = usable ? fma(rz, nrm[0], -rx * nrm[2]) : 0.0;
+        row[5] = usable ? fma(rx, nrm[1], -ry * nrm[0]) : 0.0;
+      }
+      {
+        // joint s rotates about column axis(s) of frame s-1 through the origin of frame s
+        double Rj[9], pj[3];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Rj[c] = Rw[c];
+        pj[0] = st[0]; pj[1] = st[1]; pj[2] = st[2];
+        static_for<1, S::kSeg>([&](auto sc_) {
+          constexpr int s = decltype(sc_)::value;
+          if (s <= k) {
+            double pn[3];
+            xform(Rj, pj, M->seg_t[s][0], M->seg_t[s][1], M->seg_t[s][2], pn);
+            pj[0] = pn[0]; pj[1] = pn[1]; pj[2] = pn[2];
+            constexpr int ax = S::axis(s);
+            const double ax_w[3] = {Rj[ax], Rj[3 + ax], Rj[6 + ax]};
+            const double rx = br[0] - pj[0], ry = br[1] - pj[1], rz = br[2] - pj[2];
+            const double vx = fma(ax_w[1], rz, -ax_w[2] * ry), vy = fma(ax_w[2], rx, -ax_w[0] * rz),
+                         vz = fma(ax_w[0], ry, -ax_w[1] * rx);
+            row[6 + S::joint(s)] = usable ? fma(nrm[0], vx, fma(nrm[1], vy, nrm[2] * vz)) : 0.0;
+            rot_cols<ax>(Rj, sm.cs[(2 * S::joint(s)) * kBlock + tid], sm.cs[(2 * S::joint(s) + 1) * kBlock + tid]);
+          }
+        });
+      }
+      if (in_range) {
+        if (A.av_dist) A.av_dist[q * A.ld + gi] = best;
+        if (A.av_box) A.av_box[q * A.ld + gi] = bi;
+        if (A.av_lb)
+          A.av_lb[q * A.ld + gi] = (usable && best < A.av_range) ? -A.av_gain * ((best - A.av_forbid) / (A.av_range - A.av_forbid)) : -1e6;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (A.av_p_env) A.av_p_env[(3 * q + c) * A.ld + gi] = usable ? be[c] : NAN;
+          if (A.av_p_robot) A.av_p_robot[(3 * q + c) * A.ld + gi] = usable ? br[c] : NAN;
+        }
+        if (A.av_row) {
+#pragma unroll
+          for (int c = 0; c < W; ++c) A.av_row[(static_cast<uint64_t>(W) * q + c) * A.ld + gi] = row[c];
+        }
+      }
+    }
+  }
+  if (in_range && A.av_ok) A.av_ok[gi] = ok ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------
 // small helper kernels
 // ------------------------------------------------------------------------
@@ -1427,6 +1701,19 @@ int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, 
   return hipErrorInvalidValue;
 }
 
+int launch_avoid(const EvalArgs& a, int robot_type, int n_links, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const uint64_t blocks = (a.n + kBlock - 1) / kBlock;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+  const dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
+  if (robot_type == MVK_ROBOT_HYDRUS && n_links == 4) hipLaunchKernelGGL((avoid_kernel<MVK_ROBOT_HYDRUS, 4>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 6) hipLaunchKernelGGL((avoid_kernel<MVK_ROBOT_HYDRUS, 6>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 8) hipLaunchKernelGGL((avoid_kernel<MVK_ROBOT_HYDRUS, 8>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else if (robot_type == MVK_ROBOT_DRAGON && n_links == 4) hipLaunchKernelGGL((avoid_kernel<MVK_ROBOT_DRAGON, 4>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
 int launch_edge_init(int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint64_t n_edges, void* stream) {
   if (n_edges == 0) return hipSuccess;
   hipLaunchKernelGGL(edge_init_kernel, dim3(static_cast<unsigned>((n_edges + 255) / 256)), dim3(256), 0,

@@ -210,6 +210,20 @@ class Engine:
                                                  C.byref(det)))
         return out
 
+    def collision_avoidance_batch(self, soa, layout=A.LAYOUT_POSE7, damping_gain=0.01, constraint_range=0.03,
+                                  forbidden_range=0.01, full_body=True):
+        """CollisionAvoidance::getConstraint rows for a batch (include/mvk.h)."""
+        soa = np.ascontiguousarray(soa, dtype=np.float64)
+        rows, n = soa.shape
+        assert rows == self.state_dim(layout)
+        P, W = self.model.n_prim, 6 + self.n_joint
+        out = dict(dist=np.zeros((P, n)), box=np.zeros((P, n), np.int32), p_env=np.zeros((3 * P, n)),
+                   p_robot=np.zeros((3 * P, n)), row=np.zeros((W * P, n)), lb=np.zeros((P, n)), ok=np.zeros(n, np.uint8))
+        prm = A.AvoidParams(damping_gain, constraint_range, forbidden_range, int(full_body))
+        o = A.AvoidOut(*[_ptr(out[k]) for k in ("dist", "box", "p_env", "p_robot", "row", "lb", "ok")])
+        _check(self.lib, self.lib.mvk_collision_avoidance_batch(self.ctx, _ptr(soa), n, n, layout, C.byref(prm), C.byref(o)))
+        return out
+
     def reduce_stats(self):
         s = A.Stats()
         _check(self.lib, self.lib.mvk_reduce_stats(self.ctx, C.byref(s)))

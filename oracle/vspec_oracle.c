@@ -928,3 +928,224 @@ int orc_scene_vertical_gap(double gx, double gy, double gh, int planning_walls, 
   }
   return n;
 }
+
+/* ---------------------------------------------------------------------- */
+/* collision-avoidance constraint rows                     */
+/* Restates differential_kinematics CollisionAvoidance::getConstraint           */
+/* (src/constraint/collision_avoidance.cpp:102-277): per robot collision        */
+/* primitive the minimum distance to the obstacle set with nearest points       */
+/* (:147-153), the unit normal from the environment to the robot (:255), the    */
+/* row n^T J_lin (:259-260) and the damped lower bound (:262-265,                 */
+/* constraint/base_plugin.h:108-113).  fcl::distance and                         */
+/* RobotModel::getJacobian are third-party and absent: the closed forms below    */
+/* and the column convention [root v (world), root w (world), planned joints]    */
+/* are this build's V-spec -- parity unpinned.                                   */
+/* ---------------------------------------------------------------------- */
+/* segment p0 + t d vs box: parameter, point on the segment, point on the box */
+static double seg_box_closest(const double p0[3], const double d[3], const double h[3], double y[3],
+                              double z[3]) {
+  double T[8];
+  int nt = 0;
+  T[nt++] = 0.0;
+  T[nt++] = 1.0;
+  for (int k = 0; k < 3; ++k)
+    if (d[k] != 0.0) {
+      double ta = (h[k] - p0[k]) / d[k], tb = (-h[k] - p0[k]) / d[k];
+      if (ta > 0.0 && ta < 1.0) T[nt++] = ta;
+      if (tb > 0.0 && tb < 1.0) T[nt++] = tb;
+    }
+  qsort(T, nt, sizeof(double), cmp_double);
+  double tstar;
+  if (seg_dfun(p0, d, h, 0.0) >= 0.0) tstar = 0.0;
+  else if (seg_dfun(p0, d, h, 1.0) <= 0.0) tstar = 1.0;
+  else {
+    tstar = 1.0;
+    for (int i = 1; i < nt; ++i) {
+      double fb = seg_dfun(p0, d, h, T[i]);
+      if (fb >= 0.0) {
+        double fa = seg_dfun(p0, d, h, T[i - 1]);
+        tstar = (fb > fa) ? T[i - 1] + (T[i] - T[i - 1]) * (-fa) / (fb - fa) : T[i - 1];
+        break;
+      }
+    }
+  }
+  for (int k = 0; k < 3; ++k) {
+    y[k] = p0[k] + tstar * d[k];
+    z[k] = y[k] > h[k] ? h[k] : (y[k] < -h[k] ? -h[k] : y[k]);
+  }
+  return point_box_dist(y, h);
+}
+
+/* closest pair between the 12 edges of box A (in B's frame) and solid B */
+static double box_edges_to_box_cp(const double c[3], const double R[9], const double a[3], const double b[3],
+                                  double pa[3], double pb[3]) {
+  double best = INFINITY;
+  for (int ax = 0; ax < 3; ++ax) {
+    int u = (ax + 1) % 3, v = (ax + 2) % 3;
+    for (int su = -1; su <= 1; su += 2)
+      for (int sv = -1; sv <= 1; sv += 2) {
+        double p0[3], d[3], y[3], z[3];
+        for (int k = 0; k < 3; ++k) {
+          double mid = c[k] + su * a[u] * R[3 * k + u] + sv * a[v] * R[3 * k + v];
+          p0[k] = mid - a[ax] * R[3 * k + ax];
+          d[k] = 2.0 * a[ax] * R[3 * k + ax];
+        }
+        double dist = seg_box_closest(p0, d, b, y, z);
+        if (dist < best) {
+          best = dist;
+          memcpy(pa, y, sizeof(y));
+          memcpy(pb, z, sizeof(z));
+        }
+      }
+  }
+  return best;
+}
+
+/* signed distance + nearest points in world coordinates (NaN when in contact) */
+static double prim_box_closest(int type, const double pc[3], const double pR[9], const double dim[3],
+                               const double oc[3], const double oR[9], const double oh[3], double p_robot[3],
+                               double p_env[3]) {
+  double dist;
+  p_robot[0] = p_robot[1] = p_robot[2] = p_env[0] = p_env[1] = p_env[2] = NAN;
+  if (type == MVK_PRIM_SPHERE || type == MVK_PRIM_CAPSULE) {
+    const double hl = type == MVK_PRIM_CAPSULE ? dim[1] : 0.0;
+    double ax[3] = {pR[2], pR[5], pR[8]}, aw[3], dirw[3], p0[3], d[3], y[3], z[3];
+    for (int k = 0; k < 3; ++k) {
+      aw[k] = pc[k] - hl * ax[k] - oc[k];
+      dirw[k] = 2.0 * hl * ax[k];
+    }
+    mat_t_vec(oR, aw, p0);
+    mat_t_vec(oR, dirw, d);
+    double core = seg_box_closest(p0, d, oh, y, z);
+    dist = core - dim[0];
+    if (dist > 0.0) { /* robot point: from the core towards the box by the radius */
+      double yw[3], zw[3];
+      mat_vec(oR, y, yw);
+      mat_vec(oR, z, zw);
+      for (int k = 0; k < 3; ++k) {
+        p_env[k] = oc[k] + zw[k];
+        p_robot[k] = oc[k] + yw[k] + dim[0] * (zw[k] - yw[k]) / core;
+      }
+    }
+    return dist;
+  }
+  dist = box_box_sat(pc, pR, dim, oc, oR, oh);
+  if (!(dist > 0.0)) return dist;
+  double R[9], c[3], dw[3], pa1[3], pb1[3], pa2[3], pb2[3];
+  for (int i = 0; i < 3; ++i) /* primitive in the obstacle frame */
+    for (int j = 0; j < 3; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) s += oR[3 * k + i] * pR[3 * k + j];
+      R[3 * i + j] = s;
+    }
+  for (int k = 0; k < 3; ++k) dw[k] = pc[k] - oc[k];
+  mat_t_vec(oR, dw, c);
+  double d1 = box_edges_to_box_cp(c, R, dim, oh, pa1, pb1); /* pa1 on the robot, pb1 on the box (box frame) */
+  for (int i = 0; i < 3; ++i) /* obstacle in the primitive frame */
+    for (int j = 0; j < 3; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) s += pR[3 * k + i] * oR[3 * k + j];
+      R[3 * i + j] = s;
+    }
+  for (int k = 0; k < 3; ++k) dw[k] = oc[k] - pc[k];
+  mat_t_vec(pR, dw, c);
+  double d2 = box_edges_to_box_cp(c, R, oh, dim, pa2, pb2); /* pa2 on the box, pb2 on the robot (primitive frame) */
+  double w[3];
+  if (d1 <= d2) {
+    mat_vec(oR, pa1, w); for (int k = 0; k < 3; ++k) p_robot[k] = oc[k] + w[k];
+    mat_vec(oR, pb1, w); for (int k = 0; k < 3; ++k) p_env[k] = oc[k] + w[k];
+    return d1;
+  }
+  mat_vec(pR, pa2, w); for (int k = 0; k < 3; ++k) p_env[k] = pc[k] + w[k];
+  mat_vec(pR, pb2, w); for (int k = 0; k < 3; ++k) p_robot[k] = pc[k] + w[k];
+  return d2;
+}
+
+/* One state (unpacked px..qw j1..jJ).  Arrays are per primitive q: dist[q], box[q], p_env[3q..],
+ * p_robot[3q..], row[(6+J)q..], lb[q].  Returns getConstraint's verdict: 0 when a distance <= 0. */
+int orc_avoid_state(const mvk_model* m, const mvk_box* boxes, size_t n_boxes, const mvk_params* prm,
+                    const double* st, double damping_gain, double constraint_range, double forbidden_range,
+                    int full_body, double* dist, int32_t* box, double* p_env, double* p_robot, double* row,
+                    double* lb) {
+  const int J = m->n_joint, W = 6 + J;
+  orc_out o;
+  mvk_params p = *prm;
+  p.check_collision = 0;
+  orc_eval_state(m, NULL, 0, &p, st, 1, &o); /* posed primitives (incl. gimbal frames) */
+  /* joint origins and axes in the world frame */
+  double R[9], pos[3] = {st[0], st[1], st[2]}, jo[MVK_MAX_SEG][3], ja[MVK_MAX_SEG][3];
+  quat_to_mat(st + 3, R);
+  for (int k = 1; k < m->n_seg; ++k) {
+    double off[3], Jm[9], Rn[9];
+    mat_vec(R, m->seg_t[k], off);
+    for (int c = 0; c < 3; ++c) pos[c] += off[c];
+    for (int c = 0; c < 3; ++c) { jo[k][c] = pos[c]; ja[k][c] = m->seg_axis[k] >= 0 ? R[3 * c + m->seg_axis[k]] : 0.0; }
+    if (m->seg_axis[k] >= 0) {
+      axis_rot(m->seg_axis[k], m->seg_joint[k] >= 0 ? st[7 + m->seg_joint[k]] : 0.0, Jm);
+      mat_mul(R, Jm, Rn);
+      memcpy(R, Rn, sizeof(R));
+    }
+  }
+  int ok = 1;
+  for (int q = 0; q < m->n_prim; ++q) {
+    double best = INFINITY, be[3] = {NAN, NAN, NAN}, br[3] = {NAN, NAN, NAN};
+    int bi = -1;
+    for (size_t ob = 0; ob < n_boxes; ++ob) {
+      double oR[9], oh[3] = {0.5 * boxes[ob].size[0], 0.5 * boxes[ob].size[1], 0.5 * boxes[ob].size[2]}, pr[3], pe[3];
+      quat_to_mat(boxes[ob].quat, oR);
+      double d = prim_box_closest(m->prim_type[q], o.prim_c[q], o.prim_R[q], m->prim_dim[q], boxes[ob].center, oR, oh, pr, pe);
+      if (d < best) { best = d; bi = (int)ob; memcpy(be, pe, sizeof(pe)); memcpy(br, pr, sizeof(pr)); }
+    }
+    dist[q] = best;
+    box[q] = bi;
+    for (int c = 0; c < 3; ++c) { p_env[3 * q + c] = be[c]; p_robot[3 * q + c] = br[c]; }
+    double* a = row + (size_t)W * q;
+    for (int c = 0; c < W; ++c) a[c] = 0.0;
+    lb[q] = -1e6;
+    if (bi < 0) continue;                 /* empty world: unconstrained */
+    if (!(best > 0.0)) { ok = 0; continue; } /* collision_avoidance.cpp:214-218 */
+    double n[3] = {br[0] - be[0], br[1] - be[1], br[2] - be[2]}, nn = norm3(n);
+    for (int c = 0; c < 3; ++c) n[c] /= nn;
+    if (full_body) { /* :267 zeroes the root columns otherwise */
+      double r[3] = {br[0] - st[0], br[1] - st[1], br[2] - st[2]}, rxn[3];
+      cross3(r, n, rxn);
+      for (int c = 0; c < 3; ++c) { a[c] = n[c]; a[3 + c] = rxn[c]; }
+    }
+    for (int k = 1; k <= m->prim_seg[q]; ++k) {
+      if (m->seg_joint[k] < 0) continue;
+      double r[3] = {br[0] - jo[k][0], br[1] - jo[k][1], br[2] - jo[k][2]}, v[3];
+      cross3(ja[k], r, v);
+      a[6 + m->seg_joint[k]] = dot3(n, v);
+    }
+    if (best < constraint_range) /* damplingBound(min_dist, -gain, range, forbidden) */
+      lb[q] = -damping_gain * ((best - forbidden_range) / (constraint_range - forbidden_range));
+  }
+  return ok;
+}
+
+/* SoA batch of unpacked states; outputs with row pitch ld */
+int orc_avoid_batch(const mvk_model* m, const mvk_box* boxes, size_t n_boxes, const mvk_params* prm,
+                    const double* soa, size_t n, size_t ld, double damping_gain, double constraint_range,
+                    double forbidden_range, int full_body, double* dist, int32_t* box, double* p_env,
+                    double* p_robot, double* row, double* lb, uint8_t* ok) {
+  const int J = m->n_joint, P = m->n_prim, W = 6 + J;
+  double st[MVK_MAX_STATE_DIM], d[MVK_MAX_PRIM], pe[3 * MVK_MAX_PRIM], pr[3 * MVK_MAX_PRIM],
+      rw[(6 + MVK_MAX_JOINT) * MVK_MAX_PRIM], l[MVK_MAX_PRIM];
+  int32_t b[MVK_MAX_PRIM];
+  for (size_t i = 0; i < n; ++i) {
+    for (int r = 0; r < 7 + J; ++r) st[r] = soa[(size_t)r * ld + i];
+    ok[i] = (uint8_t)orc_avoid_state(m, boxes, n_boxes, prm, st, damping_gain, constraint_range, forbidden_range,
+                                     full_body, d, b, pe, pr, rw, l);
+    for (int q = 0; q < P; ++q) {
+      dist[(size_t)q * ld + i] = d[q];
+      box[(size_t)q * ld + i] = b[q];
+      lb[(size_t)q * ld + i] = l[q];
+      for (int c = 0; c < 3; ++c) {
+        p_env[(size_t)(3 * q + c) * ld + i] = pe[3 * q + c];
+        p_robot[(size_t)(3 * q + c) * ld + i] = pr[3 * q + c];
+      }
+      for (int c = 0; c < W; ++c) row[(size_t)(W * q + c) * ld + i] = rw[W * q + c];
+    }
+  }
+  return 0;
+}

@@ -152,3 +152,21 @@ def scene_vertical_gap(gx=1.0, gy=1.0, gh=0.3, planning_walls=True, ceiling_offs
     n = lib.orc_scene_vertical_gap(C.c_double(gx), C.c_double(gy), C.c_double(gh), int(planning_walls),
                                    C.c_double(ceiling_offset), C.c_double(side_wall_width), out)
     return boxes_to_array(out, n)
+
+
+def avoid_batch(model, boxes, params, soa, damping_gain=0.01, constraint_range=0.03, forbidden_range=0.01, full_body=True):
+    """CollisionAvoidance::getConstraint restated (collision_avoidance.cpp:102-277); soa = unpacked POSE7 states."""
+    from motion_planning_amd.engine import boxes_from_array
+    lib = load()
+    soa = np.ascontiguousarray(soa, dtype=np.float64)
+    rows, n = soa.shape
+    assert rows == 7 + model.n_joint
+    P, W = model.n_prim, 6 + model.n_joint
+    barr, m = boxes_from_array(boxes)
+    out = dict(dist=np.zeros((P, n)), box=np.zeros((P, n), np.int32), p_env=np.zeros((3 * P, n)),
+               p_robot=np.zeros((3 * P, n)), row=np.zeros((W * P, n)), lb=np.zeros((P, n)), ok=np.zeros(n, np.uint8))
+    lib.orc_avoid_batch(C.byref(model), barr, C.c_size_t(m), C.byref(params), _p(soa), C.c_size_t(n), C.c_size_t(n),
+                        C.c_double(damping_gain), C.c_double(constraint_range), C.c_double(forbidden_range), int(full_body),
+                        _p(out["dist"]), _p(out["box"]), _p(out["p_env"]), _p(out["p_robot"]), _p(out["row"]),
+                        _p(out["lb"]), _p(out["ok"]))
+    return out

@@ -1,0 +1,81 @@
+"""GPU parity of the collision-avoidance rows against the CPU oracle.
+
+Reference: CollisionAvoidance::getConstraint (differential_kinematics/src/constraint/collision_avoidance.cpp:102-277).
+Bar: distances and bounds within 1e-5 relative; closest box identical; points and rows within 1e-6 wherever the
+closest pair is unique (parallel faces / edges admit a continuum of closest points: there both answers must
+realise the same distance and the rows are compared through it).
+"""
+import numpy as np
+import pytest
+
+import common
+import motion_planning_amd as mp
+import oracle_lib as O
+from motion_planning_amd import _abi as A
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,n_links,orient", [("hydrus", 4, "so3"), ("hydrus", 6, "yaw"), ("hydrus", 8, "so3"), ("dragon", 4, "so3")])
+def test_avoidance_rows_match_the_oracle(kind, n_links, orient):
+    rng = np.random.default_rng(11)
+    model = mp.make_model(kind, n_links)
+    params = mp.default_params(model, A.MODE_JOINTS_AND_BASE, A.SE3)
+    J, P, W = model.n_joint, model.n_prim, 6 + model.n_joint
+    boxes = common.random_boxes(rng, 40, [-3, -3, -2], [3, 3, 2], 0.05, 0.3, orient)
+    n = 700
+    st = np.zeros((7 + J, n))
+    st[0:3] = rng.uniform(-1.5, 1.5, (3, n))
+    st[3:7] = common.random_unit_quats(rng, n) if orient == "so3" else common.yaw_quats(rng.uniform(-np.pi, np.pi, n))
+    st[7:] = rng.uniform(-1.4, 1.4, (J, n))
+    ref = O.avoid_batch(model, boxes, params, st, 0.01, 0.08, 0.05, True)
+    eng = mp.Engine(model, boxes, params)
+    got = eng.collision_avoidance_batch(st, A.LAYOUT_POSE7, 0.01, 0.08, 0.05, True)
+    nb = eng.collision_avoidance_batch(st, A.LAYOUT_POSE7, 0.01, 0.08, 0.05, False)
+    eng.close()
+
+    assert np.array_equal(got["ok"], ref["ok"])
+    assert 0.1 < ref["ok"].mean() < 0.999
+    assert np.allclose(got["dist"], ref["dist"], rtol=1e-5, atol=1e-9)
+    tie = np.abs(got["dist"] - ref["dist"]) > 0   # equal-distance boxes may order differently only at exact ties
+    assert np.all((got["box"] == ref["box"]) | tie)
+    assert (got["box"] == ref["box"]).mean() > 0.999
+    assert np.allclose(got["lb"], ref["lb"], rtol=1e-5, atol=1e-9)
+    sep = ref["dist"] > 0
+    pe_g, pe_r = got["p_env"].reshape(P, 3, n), ref["p_env"].reshape(P, 3, n)
+    pr_g, pr_r = got["p_robot"].reshape(P, 3, n), ref["p_robot"].reshape(P, 3, n)
+    assert np.array_equal(np.isnan(pe_g[:, 0]), ~sep) and np.array_equal(np.isnan(pr_g[:, 0]), ~sep)
+    # the points realise the distance
+    assert np.allclose(np.linalg.norm(pr_g - pe_g, axis=1)[sep], got["dist"][sep], rtol=1e-9, atol=1e-12)
+    same_pts = (np.abs(pe_g - pe_r).max(1) < 1e-6) & (np.abs(pr_g - pr_r).max(1) < 1e-6)
+    # yaw-only worlds put vertical robot edges parallel to vertical box faces: a continuum of closest points along z
+    assert same_pts[sep].mean() > (0.97 if orient == "so3" else 0.9), same_pts[sep].mean()
+    if orient == "yaw":
+        same_xy = (np.abs(pe_g - pe_r)[:, :2].max(1) < 1e-6) & (np.abs(pr_g - pr_r)[:, :2].max(1) < 1e-6)
+        assert same_xy[sep].mean() > 0.98, same_xy[sep].mean()   # the rest: horizontal faces over each other
+    rows_g, rows_r = got["row"].reshape(P, W, n), ref["row"].reshape(P, W, n)
+    sel = sep & same_pts
+    assert np.allclose(rows_g.transpose(0, 2, 1)[sel], rows_r.transpose(0, 2, 1)[sel], atol=1e-6)
+    assert np.all(rows_g.transpose(0, 2, 1)[~sep] == 0.0)
+    # not full body: root columns zero, joint columns unchanged
+    rows_nb = nb["row"].reshape(P, W, n)
+    assert np.all(rows_nb[:, :6] == 0.0) and np.array_equal(rows_nb[:, 6:], rows_g[:, 6:])
+
+
+def test_avoidance_empty_world_and_ragged_sizes():
+    model = mp.make_model("hydrus", 4)
+    params = mp.default_params(model, A.MODE_JOINTS_AND_BASE, A.SE2)
+    rng = np.random.default_rng(2)
+    st = common.hydrus_states(rng, 130, model.n_joint)
+    eng = mp.Engine(model, np.zeros((0, 10)), params)
+    out = eng.collision_avoidance_batch(st)
+    assert np.all(np.isinf(out["dist"])) and np.all(out["box"] == -1) and np.all(out["lb"] == -1e6) and np.all(out["ok"] == 1)
+    boxes = common.random_boxes(rng, 10, [-2, -2, -1], [4, 2, 1], 0.05, 0.3, "yaw")
+    eng.set_scene(boxes)
+    full = eng.collision_avoidance_batch(st)
+    ref = O.avoid_batch(model, boxes, params, st)
+    assert np.allclose(full["dist"], ref["dist"], rtol=1e-5, atol=1e-9)
+    for n in (1, 63, 65):
+        part = eng.collision_avoidance_batch(st[:, :n])
+        assert np.array_equal(part["dist"], full["dist"][:, :n]) and np.array_equal(part["ok"], full["ok"][:n])
+    eng.close()
