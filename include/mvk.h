@@ -392,6 +392,37 @@ int mvk_path_log_save(const char* file, const mvk_path_log* hdr, const double* s
 /* reads the header and up to cap states; returns the number of states in the file */
 int mvk_path_log_load(const char* file, int n_joint, mvk_path_log* hdr, double* states, int cap);
 
+/* ---- path post-processing -------------------------------- *
+ * What squeeze_motion_planner::Base::plan runs on the planner's discrete path
+ * (squeeze_navigation/include/squeeze_navigation/planner/base_plugin.h:72-85).
+ * "cog state" rows: CoG position, desired baselink attitude (= root attitude, the baselink is
+ * the root link: motion_planning.cpp:188), joints -- the triple MultilinkState keeps. */
+/* MultilinkState::convertRootPose2CogPose / convertCogPose2RootPose
+ * (aerial_motion_planning_msgs/src/multilink_state.cpp:98-118 / 42-61); host, one state */
+int mvk_root_to_cog(const mvk_model* model, const double* root_state /*[7+J]*/, double* cog_state);
+int mvk_cog_to_root(const mvk_model* model, const double* cog_state /*[7+J]*/, double* root_state);
+/* ContinuousPathGenerator::discretePathResampling
+ * (aerial_motion_planning_msgs/src/continuous_path_generator.cpp:119-230); parameters
+ * resampling_angular_rate (1.0) and resampling_seg_diff_thresh (0.2) (:124-125).
+ * States are row major [n][7+J]; returns the number of states written, negative on error.
+ * discretePathSmoothing (:57-117) is not provided: its FIR filters are in an absent package. */
+int mvk_path_resample(const double* cog_states, int n, int n_joint, double angular_rate, double seg_diff_thresh,
+                      double* out, int cap);
+/* ContinuousPathGenerator::calcContinuousPath (:232-282) + BsplineRos::initialize
+ * (bspline_ros/src/bspline_ros.cpp:45-86): clamped uniform B-spline of `degree` (bspline_degree,
+ * default 5) over [0, period] through the control points (cog xyz, roll pitch yaw with a
+ * continuous yaw, joints), first and last state doubled.  Curve dimension = 6 + J. */
+typedef struct mvk_spline mvk_spline;
+mvk_spline* mvk_spline_create(const double* cog_states, int n, int n_joint, double period, int degree);
+void mvk_spline_destroy(mvk_spline* s);
+int mvk_spline_dim(const mvk_spline* s);
+/* BsplineRos::evaluate (bspline_ros.cpp:88-110; getPositionVector / getVelocityVector of
+ * continuous_path_generator.cpp:47-55): derive-th derivative at nt times (clamped to the period).
+ * Host: out [nt][dim] row major.  Device: d_t [nt], d_out [dim][ld] SoA, one lane per time. */
+int mvk_spline_eval(const mvk_spline* s, const double* t, int nt, int derive, double* out);
+int mvk_spline_eval_dev(mvk_spline* s, int device, const double* d_t, size_t nt, int derive, double* d_out,
+                        size_t ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,6 +151,14 @@ PROTOTYPES = {
     "mvk_plan_rrt_connect_cb": (ip, [PP, ip, C.POINTER(Checker), C.POINTER(PlanRequest), vp, ip, C.POINTER(PlanResult)]),
     "mvk_plan_rrt_connect": (ip, [vp, C.POINTER(PlanRequest), vp, ip, C.POINTER(PlanResult)]),
     "mvk_path_densify": (ip, [PP, ip, vp, ip, vp, ip]),
+    "mvk_root_to_cog": (ip, [PM, vp, vp]),
+    "mvk_cog_to_root": (ip, [PM, vp, vp]),
+    "mvk_path_resample": (ip, [vp, ip, ip, d, d, vp, ip]),
+    "mvk_spline_create": (vp, [vp, ip, ip, d, ip]),
+    "mvk_spline_destroy": (None, [vp]),
+    "mvk_spline_dim": (ip, [vp]),
+    "mvk_spline_eval": (ip, [vp, vp, ip, ip, vp]),
+    "mvk_spline_eval_dev": (ip, [vp, ip, vp, sz, ip, vp, sz, vp]),
     "mvk_path_log_save": (ip, [C.c_char_p, C.POINTER(PathLog), vp]),
     "mvk_path_log_load": (ip, [C.c_char_p, ip, C.POINTER(PathLog), vp, ip]),
 }

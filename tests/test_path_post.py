@@ -1,0 +1,165 @@
+"""Host tests of the path post-processing: MultilinkState root <-> CoG conversion,
+discrete-path resampling (continuous_path_generator.cpp:119-230) and the clamped uniform B-spline
+(continuous_path_generator.cpp:232-282, bspline_ros.cpp:45-110).
+
+tf and tinyspline are absent; the spline is checked against scipy.interpolate.BSpline (an independent
+implementation of the same published definition), the resampler against a line-by-line Python restatement.
+"""
+import numpy as np
+import pytest
+from scipy.interpolate import BSpline
+
+import common
+import motion_planning_amd as mp
+import oracle_lib as O
+from motion_planning_amd import _abi as A
+from motion_planning_amd import path as PP
+
+
+def _angle(a, b):
+    s = np.sqrt(np.dot(a, a) * np.dot(b, b))
+    return 2.0 * np.arccos(min(1.0, abs(np.dot(a, b)) / s))
+
+
+def _slerp(a, b, t):
+    th = _angle(a, b) / 2.0
+    if th == 0.0:
+        return a.copy()
+    d = 1.0 / np.sin(th)
+    s0, s1 = np.sin((1 - t) * th), np.sin(t * th)
+    return (a * s0 + (-b if np.dot(a, b) < 0 else b) * s1) * d
+
+
+def resample_py(path, rate=1.0, thresh=0.2):
+    """continuous_path_generator.cpp:119-230 restated line by line"""
+    def metric(a, b):
+        return np.linalg.norm(a[:3] - b[:3]) + rate * abs(_angle(a[3:7], b[3:7]))
+    n = len(path)
+    ave = sum(metric(path[i], path[i + 1]) for i in range(n - 1)) / n
+    res = [path[0].copy()]
+    delta, not_enough, i = 0.0, False, 1
+    while i < n:
+        prev, cur = path[i - 1], path[i]
+        if delta == 0:
+            delta = metric(res[-1], cur)
+        if not_enough:
+            delta += metric(prev, cur)
+            not_enough = False
+        if abs(delta - ave) < thresh * ave:
+            res.append(cur.copy()); delta = 0; i += 1
+        elif delta > ave:
+            r = 1 - (delta - ave) / metric(prev, cur)
+            s = prev * (1 - r) + cur * r
+            s[3:7] = _slerp(prev[3:7], cur[3:7], r)
+            res.append(s)
+            delta = metric(res[-1], cur)
+        else:
+            not_enough = True; i += 1
+    return np.array(res)
+
+
+def _random_path(rng, n, J):
+    p = np.zeros((n, 7 + J))
+    p[:, 0:3] = np.cumsum(rng.normal(scale=0.1, size=(n, 3)) * rng.uniform(0.1, 2.0, (n, 1)), axis=0)
+    yaw = np.cumsum(rng.normal(scale=0.3, size=n)) + 2.5
+    p[:, 3:7] = common.yaw_quats(yaw).T
+    tilt = common.random_unit_quats(rng, n).T * 0.05
+    p[:, 3:7] += tilt
+    p[:, 3:7] /= np.linalg.norm(p[:, 3:7], axis=1, keepdims=True)
+    p[:, 7:] = np.cumsum(rng.normal(scale=0.05, size=(n, J)), axis=0)
+    return p
+
+
+def test_root_cog_conversions_agree_with_the_oracle_and_invert():
+    rng = np.random.default_rng(1)
+    for kind, nl in (("hydrus", 6), ("dragon", 4)):
+        model = mp.make_model(kind, nl)
+        params = mp.default_params(model, A.MODE_JOINTS_AND_BASE, A.SE3)
+        J = model.n_joint
+        st = np.zeros((7 + J, 20))
+        st[0:3] = rng.uniform(-2, 2, (3, 20))
+        st[3:7] = common.random_unit_quats(rng, 20)
+        st[7:] = rng.uniform(-1.5, 1.5, (J, 20))
+        ref = O.eval_batch(model, np.zeros((0, 10)), params, st)
+        for i in range(20):
+            cog = PP.root_to_cog(model, st[:, i])
+            assert np.allclose(cog[0:3], ref["cog"][:, i], atol=1e-12)          # multilink_state.cpp:115-117
+            assert np.array_equal(cog[3:], st[3:, i])                            # baselink attitude = root attitude
+            assert np.allclose(PP.cog_to_root(model, cog), st[:, i], atol=1e-12)  # :42-61 inverts :98-118
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_resampling_matches_the_line_by_line_restatement(seed):
+    rng = np.random.default_rng(seed)
+    path = _random_path(rng, 60, 3)
+    got = PP.resample(path, 1.0, 0.2)
+    ref = resample_py(path, 1.0, 0.2)
+    assert got.shape == ref.shape and np.allclose(got, ref, atol=1e-12)
+    assert np.array_equal(got[0], path[0])
+    # spacing: every step but those ending on a raw state inside the tolerance is the average step
+    def metric(a, b):
+        return np.linalg.norm(a[:3] - b[:3]) + abs(_angle(a[3:7], b[3:7]))
+    ave = sum(metric(path[i], path[i + 1]) for i in range(59)) / 60
+    steps = np.array([metric(got[i], got[i + 1]) for i in range(len(got) - 1)])
+    assert np.all(steps < 1.2 * ave + 1e-9)
+    got2 = PP.resample(path, 0.3, 0.1)
+    assert np.allclose(got2, resample_py(path, 0.3, 0.1), atol=1e-12)
+
+
+def test_resampling_of_an_evenly_spaced_path_returns_it():
+    p = np.zeros((10, 10))
+    p[:, 0] = np.arange(10) * 0.1
+    p[:, 6] = 1.0
+    got = PP.resample(p)
+    # ave = length / n (not n - 1), as the reference computes it (:142): every raw step is within 20 % of it
+    assert np.allclose(got, p)
+    with pytest.raises(mp.MvkError):
+        PP.resample(np.zeros((0, 10)))
+
+
+@pytest.mark.parametrize("degree", [3, 5])
+def test_spline_matches_scipy_and_has_zero_end_velocity(degree):
+    rng = np.random.default_rng(5)
+    J, n, period = 5, 30, 40.0
+    path = _random_path(rng, n, J)
+    sp = PP.Spline(path, period, degree)
+    assert sp.dim == 6 + J
+    t = np.concatenate([np.linspace(0, period, 301), [-3.0, period + 2.0]])
+    # control points as calcContinuousPath builds them (:240-271)
+    def rpy(q):
+        x, y, z, w = q / np.linalg.norm(q)
+        r20, r21, r22 = 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)
+        r10, r00 = 2 * (x * y + w * z), 1 - 2 * (y * y + z * z)
+        pitch = -np.arcsin(r20)
+        return np.arctan2(r21 / np.cos(pitch), r22 / np.cos(pitch)), pitch, np.arctan2(r10 / np.cos(pitch), r00 / np.cos(pitch))
+    ctrl, prev = [], None
+    for i in [0] + list(range(n)) + [n - 1]:
+        r, p, y = rpy(path[i, 3:7])
+        if prev is None:
+            prev = y
+        while y - prev > np.pi:
+            y -= 2 * np.pi
+        while y - prev < -np.pi:
+            y += 2 * np.pi
+        prev = y
+        ctrl.append([*path[i, 0:3], r, p, y, *path[i, 7:]])
+    ctrl = np.array(ctrl)
+    nc = len(ctrl)
+    knots = np.concatenate([np.zeros(degree + 1), np.arange(1, nc - degree) / (nc - degree), np.ones(degree + 1)])
+    ref = BSpline(knots, ctrl, degree)
+    x = np.clip(t, 0, period) / period
+    assert np.allclose(sp.eval(t), ref(x), atol=1e-10)
+    for k in range(1, degree):
+        assert np.allclose(sp.eval(t, k), ref.derivative(k)(x) / period ** k, rtol=1e-8, atol=1e-8 * max(1.0, (nc / period) ** k))
+    # start / goal are reached with zero velocity (the doubled end control points, :240-246)
+    ends = sp.eval([0.0, period])
+    assert np.allclose(ends[0], ctrl[0]) and np.allclose(ends[1], ctrl[-1])
+    assert np.allclose(sp.eval([0.0, period], 1), 0.0, atol=1e-12)
+    # yaw stays continuous although the quaternion yaw wraps
+    yaw = sp.eval(np.linspace(0, period, 2000))[:, 5]
+    assert np.abs(np.diff(yaw)).max() < 0.2
+    with pytest.raises(mp.MvkError):
+        sp.eval([0.0], degree)          # BsplineRos keeps degree-1 derivatives (bspline_ros.cpp:83)
+    with pytest.raises(mp.MvkError):
+        PP.Spline(path[:2], period, 5)  # control points <= degree (bspline_ros.cpp:47-51)
+    sp.close()
