@@ -52,24 +52,43 @@ def cpu_baseline(w, budget_s=12.0):
             "sample": f"first {n2} samples of the {w.name} batch, flag-only predicate, {cores} threads"}
 
 
-def rrt_connect_gap_pass(repeats=5):
+def rrt_connect_gap_pass(seeds=10, batch=256):
     """Second half of BASELINE.json's metric: RRT-Connect gap-pass solve time (config c1: HYDRUS quad through
-    the default horizontal gap world) on the GPU checker.  Median over seeds of the search wall time."""
+    the default horizontal gap world) on the GPU checker; median over seeds of the search wall time.  The same
+    planner is run once on the CPU checker (config 0 of BASELINE.json, the oracle behind the planner's callback
+    form) for comparison."""
     import common
     import motion_planning_amd as mp
+    import oracle_lib as O
+    from motion_planning_amd import _abi as A
     from motion_planning_amd import planner as PL
     model, params, boxes, start, goal = common.config1()
     eng = mp.Engine(model, boxes, params)
+    PL.plan_rrt_connect(eng, start, goal, time_limit_s=5.0, seed=99, batch=batch)   # warm-up (buffers, worker threads)
     runs = []
-    for seed in range(1, repeats + 1):
-        wp, info = PL.plan_rrt_connect(eng, start, goal, time_limit_s=20.0, seed=seed, batch=64)
+    for seed in range(1, seeds + 1):
+        wp, info = PL.plan_rrt_connect(eng, start, goal, time_limit_s=20.0, seed=seed, batch=batch)
         runs.append(dict(seed=seed, solved=int(info["solved"]), solve_ms=info["solve_ms"], iterations=int(info["iterations"]),
                          edge_checks=int(info["edge_checks"]), state_checks_in_edges=int(info["edge_steps"]),
                          waypoints=int(info["n_waypoints"])))
     eng.close()
     ok = [r["solve_ms"] for r in runs if r["solved"]]
-    return {"config": "c1: HYDRUS quad, joints+base SE2, horizontal gap world (4 boxes), batch 64", "unit": "ms",
-            "median_solve_ms": float(np.median(ok)) if ok else None, "solved": len(ok), "runs": runs}
+    out = {"config": f"c1: HYDRUS quad, joints+base SE2, horizontal gap world (4 boxes), {batch} extensions per iteration",
+           "unit": "ms", "median_solve_ms": float(np.median(ok)) if ok else None, "mean_solve_ms": float(np.mean(ok)) if ok else None,
+           "max_solve_ms": float(np.max(ok)) if ok else None, "solved": len(ok), "seeds": seeds, "runs": runs}
+
+    def cs(soa):
+        return O.eval_batch(model, boxes, params, soa, A.LAYOUT_OMPL)["flags"]
+
+    def cm(s1, s2, nd):
+        okk, first, _ = O.check_motion_batch(model, boxes, params, s1, s2, nd)
+        return okk, first
+    t0 = time.perf_counter()
+    wp, info = PL.plan_rrt_connect_cb(params, model.n_joint, cs, cm, start, goal, time_limit_s=30.0, seed=1, batch=batch)
+    out["cpu_checker"] = {"kind": "port", "seed": 1, "solved": int(info["solved"]), "solve_ms": info["solve_ms"],
+                          "wall_ms": (time.perf_counter() - t0) * 1e3, "edge_checks": int(info["edge_checks"]),
+                          "note": "same planner and seed on the single-thread CPU checker (oracle), 30 s limit"}
+    return out
 
 
 def edge_checks(dev):

@@ -57,6 +57,26 @@ struct Buf {  // grow-only device buffer
   }
 };
 
+struct PinBuf {  // grow-only pinned host buffer (async copies from pageable memory are staged and slow)
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return MVK_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return MVK_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 void quat_to_rows(const double q[4], double R[9]) {
   const double x = q[0], y = q[1], z = q[2], w = q[3];
   const double s = 2.0 / (x * x + y * y + z * z + w * w);
@@ -93,6 +113,9 @@ struct mvk_ctx {
   hipStream_t stream = nullptr;
   // staging for the host-pointer entry points
   Buf in_a, in_b, flags, band, mind, margin, det[6], nd, ok, first, edge_off, av[7];
+  // host edge checks (the planner's inner loop): one pinned upload blob, one pinned download
+  Buf edge_blob;
+  PinBuf pin_up, pin_down;
   // statistics of the last FULL batch
   Buf partial, stats_out;
   uint64_t last_blocks = 0, last_n = 0;
@@ -471,6 +494,9 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
                 &c->partial, &c->stats_out, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
   for (Buf* b : all) b->release();
+  c->edge_blob.release();
+  c->pin_up.release();
+  c->pin_down.release();
   delete c;
 }
 
@@ -718,7 +744,7 @@ namespace {
 // d_edge_off: exclusive prefix of clamp(nd,1) (device), total = number of steps
 int run_edges_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_edges, size_t ld,
                   const int32_t* d_nd, const int64_t* d_edge_off, uint64_t total, int32_t nd_uniform,
-                  uint8_t* d_ok, int32_t* d_first, hipStream_t s) {
+                  uint8_t* d_ok, int32_t* d_first, hipStream_t s, bool first_is_initialised = false) {
   EvalArgs a;
   base_args(c, a);
   a.s1 = d_s1;
@@ -733,7 +759,7 @@ int run_edges_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_e
   a.first_invalid = d_first;
   c->stats_valid = false;
   if (int rc = prepare_queue(c, a, total)) return rc;
-  int e = launch_edge_init(d_first, d_nd, a.nd_uniform, n_edges, s);
+  int e = first_is_initialised ? static_cast<int>(hipSuccess) : launch_edge_init(d_first, d_nd, a.nd_uniform, n_edges, s);
   if (e == hipSuccess) e = launch_eval(a, c->model.robot_type, c->model.n_rotor, true, s, c->profiling ? c->ev : nullptr);
   c->timed = c->profiling;
   if (e == hipSuccess && d_ok) e = launch_edge_finish(d_first, d_nd, a.nd_uniform, d_ok, n_edges, s);
@@ -793,35 +819,49 @@ extern "C" int mvk_check_motion_batch(mvk_ctx* c, const double* s1, const double
   if (!ok && !first_invalid) return fail(MVK_ERR_INVALID_ARG, "no output requested");
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  const int rows = space_dim(&c->params, c->model.n_joint);
+  // This is the planner's inner loop (hundreds of small calls per solve), so the call is shaped for
+  // latency: everything the kernels read -- both state blocks, the per-edge counts, their prefix and
+  // the initial first_invalid = nd + 1 -- is packed into ONE pinned blob and uploaded with one copy;
+  // the verdict comes back with one copy (ok is derived from first_invalid on the host).
+  const size_t rows = static_cast<size_t>(space_dim(&c->params, c->model.n_joint));
   const size_t dld = round_up(n_edges, 64);
-  if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
-  if (int rc = c->in_b.reserve(dld * rows * sizeof(double))) return rc;
-  if (int rc = c->first.reserve(dld * sizeof(int32_t))) return rc;
-  if (int rc = c->ok.reserve(dld)) return rc;
-  if (int rc = copy_rows(c->in_a.p, dld, s1, ld, sizeof(double), n_edges, rows, hipMemcpyHostToDevice, s)) return rc;
-  if (int rc = copy_rows(c->in_b.p, dld, s2, ld, sizeof(double), n_edges, rows, hipMemcpyHostToDevice, s)) return rc;
-  uint64_t total = 0;
-  const int32_t* d_nd = nullptr;
-  const int64_t* d_off = nullptr;
-  std::vector<int64_t> off;
-  if (nd) {
-    prefix_counts(nd, n_edges, off, total);
-    if (int rc = c->nd.reserve(n_edges * sizeof(int32_t))) return rc;
-    if (int rc = c->edge_off.reserve(n_edges * sizeof(int64_t))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->nd.p, nd, n_edges * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->edge_off.p, off.data(), n_edges * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    d_nd = static_cast<const int32_t*>(c->nd.p);
-    d_off = static_cast<const int64_t*>(c->edge_off.p);
-  } else {
-    total = static_cast<uint64_t>(n_edges) * static_cast<uint64_t>(nd_uniform < 1 ? 1 : nd_uniform);
+  const size_t off_s2 = rows * dld * sizeof(double), off_off = 2 * off_s2, off_nd = off_off + dld * sizeof(int64_t),
+               off_first = off_nd + dld * sizeof(int32_t), bytes = off_first + dld * sizeof(int32_t);
+  if (int rc = c->pin_up.reserve(bytes)) return rc;
+  if (int rc = c->pin_down.reserve(dld * sizeof(int32_t))) return rc;
+  if (int rc = c->edge_blob.reserve(bytes)) return rc;
+  char* up = static_cast<char*>(c->pin_up.p);
+  double* h1 = reinterpret_cast<double*>(up);
+  double* h2 = reinterpret_cast<double*>(up + off_s2);
+  int64_t* hoff = reinterpret_cast<int64_t*>(up + off_off);
+  int32_t* hnd = reinterpret_cast<int32_t*>(up + off_nd);
+  int32_t* hfirst = reinterpret_cast<int32_t*>(up + off_first);
+  for (size_t r = 0; r < rows; ++r) {
+    std::memcpy(h1 + r * dld, s1 + r * ld, n_edges * sizeof(double));
+    std::memcpy(h2 + r * dld, s2 + r * ld, n_edges * sizeof(double));
   }
-  if (int rc = run_edges_dev(c, static_cast<const double*>(c->in_a.p), static_cast<const double*>(c->in_b.p),
-                             n_edges, dld, d_nd, d_off, total, nd_uniform, static_cast<uint8_t*>(c->ok.p),
-                             static_cast<int32_t*>(c->first.p), s))
+  uint64_t total = 0;
+  const int32_t nu = nd_uniform < 1 ? 1 : nd_uniform;
+  for (size_t e = 0; e < n_edges; ++e) {
+    const int32_t v = nd ? (nd[e] < 1 ? 1 : nd[e]) : nu;
+    hoff[e] = static_cast<int64_t>(total);
+    hnd[e] = v;
+    hfirst[e] = v + 1;
+    total += static_cast<uint64_t>(v);
+  }
+  char* dev = static_cast<char*>(c->edge_blob.p);
+  HIP_TRY(hipMemcpyAsync(dev, up, bytes, hipMemcpyHostToDevice, s));
+  if (int rc = run_edges_dev(c, reinterpret_cast<const double*>(dev), reinterpret_cast<const double*>(dev + off_s2), n_edges, dld,
+                             nd ? reinterpret_cast<const int32_t*>(dev + off_nd) : nullptr,
+                             nd ? reinterpret_cast<const int64_t*>(dev + off_off) : nullptr, total, nu, nullptr,
+                             reinterpret_cast<int32_t*>(dev + off_first), s, /*first_is_initialised=*/true))
     return rc;
-  if (ok) HIP_TRY(hipMemcpyAsync(ok, c->ok.p, n_edges, hipMemcpyDeviceToHost, s));
-  if (first_invalid) HIP_TRY(hipMemcpyAsync(first_invalid, c->first.p, n_edges * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  int32_t* down = static_cast<int32_t*>(c->pin_down.p);
+  HIP_TRY(hipMemcpyAsync(down, dev + off_first, n_edges * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  for (size_t e = 0; e < n_edges; ++e) {
+    if (first_invalid) first_invalid[e] = down[e];
+    if (ok) ok[e] = down[e] == hnd[e] + 1 ? 1 : 0;
+  }
   return MVK_OK;
 }

@@ -13,8 +13,13 @@
 // launch; the connect step is ONE more launch whose first_invalid output says how
 // far each straight connection got (the greedy repeat-extend of RRT-Connect
 // collapses into "advance to the last valid interpolation step").
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -59,13 +64,89 @@ struct Tree {
   int dim;
   std::vector<double> states;  // row-major [n][dim]
   std::vector<int> parent;
+  std::vector<std::vector<double>> col;  // the same states column-wise, for the vectorised nearest search
   int size() const { return static_cast<int>(parent.size()); }
   const double* at(int i) const { return states.data() + static_cast<size_t>(i) * dim; }
   int add(const double* s, int par) {
     states.insert(states.end(), s, s + dim);
     parent.push_back(par);
+    if (col.empty()) col.resize(dim);
+    for (int c = 0; c < dim; ++c) col[c].push_back(s[c]);
     return size() - 1;
   }
+};
+
+// A few persistent worker threads for the nearest-neighbour searches of a batch: with the validity
+// checks on the GPU, the linear scans over the trees are what is left on the host's critical path.
+class Workers {
+ public:
+  static Workers& get() {
+    static Workers w;
+    return w;
+  }
+  int count() const { return static_cast<int>(th_.size()) + 1; }
+  // runs fn(k) for k in [0, n), the caller taking part
+  void parallel_for(int n, const std::function<void(int)>& fn) {
+    if (n <= 1 || th_.empty()) {
+      for (int k = 0; k < n; ++k) fn(k);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn;
+      n_ = n;
+      next_.store(0);
+      pending_ = static_cast<int>(th_.size());
+      ++epoch_;
+    }
+    cv_.notify_all();
+    for (int k; (k = next_.fetch_add(1)) < n;) fn(k);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  Workers() {
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = hw > 2 ? static_cast<int>(hw > 16 ? 8 : hw / 2) - 1 : 0;
+    for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
+  }
+  ~Workers() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)>* fn;
+      int n;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (stop_) return;
+        fn = fn_;
+        n = n_;
+      }
+      for (int k; (k = next_.fetch_add(1)) < n;) (*fn)(k);
+      std::lock_guard<std::mutex> lk(m_);
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, pending_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
 };
 
 // uniform sample of the planner's space (OMPL's default samplers: box-uniform
@@ -91,14 +172,54 @@ void sample_uniform(const mvk_params& p, int J, Rng& rng, double* s) {
     for (int j = 0; j < J; ++j) s[off + j] = rng.uniform(p.joint_low[j], p.joint_high[j]);
 }
 
-int nearest(const mvk_params& p, int J, const Tree& t, const double* s, double* dist_out) {
+// nearest tree node under the space's distance (mvk_space_distance), the tree read column-wise so
+// that the per-node arithmetic vectorises; `scratch` holds one distance per node
+int nearest(const mvk_params& p, int J, const Tree& t, const double* s, double* dist_out, std::vector<double>& scratch) {
+  const int n = t.size();
+  scratch.assign(n, 0.0);
+  double* acc = scratch.data();
+  const bool has_base = p.planning_mode != MVK_MODE_ONLY_JOINTS, has_joints = p.planning_mode != MVK_MODE_ONLY_BASE;
+  const bool se2 = p.motion_type == MVK_SE2;
+  const int nb = has_base ? (se2 ? 3 : 7) : 0, nt = se2 ? 2 : 3;
+  if (has_joints && J > 0) {
+    for (int j = 0; j < J; ++j) {
+      const double* c = t.col[nb + j].data();
+      const double q = s[nb + j];
+      for (int i = 0; i < n; ++i) { const double d = c[i] - q; acc[i] += d * d; }
+    }
+    const double w = has_base ? p.joint_subspace_weight : 1.0;
+    for (int i = 0; i < n; ++i) acc[i] = w * std::sqrt(acc[i]);
+  }
+  if (has_base) {
+    std::vector<double> tr(n, 0.0);
+    for (int k = 0; k < nt; ++k) {
+      const double* c = t.col[k].data();
+      const double q = s[k];
+      for (int i = 0; i < n; ++i) { const double d = c[i] - q; tr[i] += d * d; }
+    }
+    if (se2) {
+      const double* c = t.col[2].data();
+      const double q = s[2];
+      for (int i = 0; i < n; ++i) {
+        double g = std::fabs(c[i] - q);
+        g = g > kPi ? 2.0 * kPi - g : g;
+        acc[i] = (std::sqrt(tr[i]) + 0.5 * g) + acc[i];
+      }
+    } else {
+      const double *c0 = t.col[3].data(), *c1 = t.col[4].data(), *c2 = t.col[5].data(), *c3 = t.col[6].data();
+      for (int i = 0; i < n; ++i) {
+        const double dq = std::fabs(c0[i] * s[3] + c1[i] * s[4] + c2[i] * s[5] + c3[i] * s[6]);
+        const double arc = dq > 1.0 - 1e-9 ? 0.0 : std::acos(dq);
+        acc[i] = (std::sqrt(tr[i]) + arc) + acc[i];
+      }
+    }
+  }
   int best = 0;
   double bd = INFINITY;
-  for (int i = 0; i < t.size(); ++i) {
-    const double d = mvk_space_distance(&p, J, t.at(i), s);
-    if (d < bd) { bd = d; best = i; }
-  }
-  *dist_out = bd;
+  for (int i = 0; i < n; ++i)
+    if (acc[i] < bd) { bd = acc[i]; best = i; }
+  // report the distance exactly as the space computes it (the scan may differ in the last bit)
+  *dist_out = mvk_space_distance(&p, J, t.at(best), s);
   return best;
 }
 
@@ -156,7 +277,7 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
   const double range = req->range > 0.0 ? req->range : 0.2 * mvk_space_max_extent(&p, J);
   const int batch = req->batch < 1 ? 1 : req->batch;
   Rng rng(req->seed);
-  Tree tree[2] = {Tree{dim, {}, {}}, Tree{dim, {}, {}}};
+  Tree tree[2] = {Tree{dim, {}, {}, {}}, Tree{dim, {}, {}, {}}};
   tree[0].add(req->start, -1);
   tree[1].add(req->goal, -1);
   EdgeBatch eb;
@@ -164,7 +285,6 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
   int link[2] = {-1, -1};  // indices of the two nodes that meet (same state in both trees)
   bool solved = false;
   int cur = 0;
-  std::vector<double> sample(dim);
 
   while (!solved) {
     if (req->max_iterations > 0 && out->iterations >= static_cast<uint64_t>(req->max_iterations)) break;
@@ -176,13 +296,25 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
     std::vector<const double*> from;
     std::vector<std::vector<double>> to;
     std::vector<int> from_idx;
+    std::vector<std::vector<double>> samples(batch, std::vector<double>(dim));
+    for (int k = 0; k < batch; ++k) sample_uniform(p, J, rng, samples[k].data());
+    std::vector<int> near_a(batch);
+    std::vector<double> dist_a(batch);
+    {
+      const bool wide = static_cast<int64_t>(batch) * ta.size() > 20000;
+      auto job = [&](int k) {
+        thread_local std::vector<double> scratch;
+        near_a[k] = nearest(p, J, ta, samples[k].data(), &dist_a[k], scratch);
+      };
+      if (wide) Workers::get().parallel_for(batch, job);
+      else for (int k = 0; k < batch; ++k) job(k);
+    }
     for (int k = 0; k < batch; ++k) {
-      sample_uniform(p, J, rng, sample.data());
-      double d;
-      const int ni = nearest(p, J, ta, sample.data(), &d);
+      const double d = dist_a[k];
+      const int ni = near_a[k];
       std::vector<double> tgt(dim);
-      if (d > range) mvk_space_interpolate(&p, J, ta.at(ni), sample.data(), range / d, tgt.data());
-      else tgt = sample;
+      if (d > range) mvk_space_interpolate(&p, J, ta.at(ni), samples[k].data(), range / d, tgt.data());
+      else tgt = samples[k];
       if (!(d > 0.0)) continue;
       from_idx.push_back(ni);
       to.push_back(std::move(tgt));
@@ -201,12 +333,19 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
     from.clear();
     std::vector<std::vector<double>> goal_states;
     std::vector<int> near_idx;
-    for (int fi : fresh) {
-      double d;
-      const int ni = nearest(p, J, tb, ta.at(fi), &d);
-      near_idx.push_back(ni);
-      goal_states.emplace_back(ta.at(fi), ta.at(fi) + dim);
+    near_idx.resize(fresh.size());
+    {
+      const int nf = static_cast<int>(fresh.size());
+      const bool wide = static_cast<int64_t>(nf) * tb.size() > 20000;
+      auto job = [&](int e) {
+        thread_local std::vector<double> scratch;
+        double d;
+        near_idx[e] = nearest(p, J, tb, ta.at(fresh[e]), &d, scratch);
+      };
+      if (wide) Workers::get().parallel_for(nf, job);
+      else for (int e = 0; e < nf; ++e) job(e);
     }
+    for (int fi : fresh) goal_states.emplace_back(ta.at(fi), ta.at(fi) + dim);
     for (int ni : near_idx) from.push_back(tb.at(ni));
     eb.pack(from, goal_states, p, J);
     if (int rc = ck->check_motions(ck->user, eb.a.data(), eb.b.data(), fresh.size(), fresh.size(), eb.nd.data(), eb.ok.data(), eb.first.data())) return rc;
