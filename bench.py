@@ -171,24 +171,33 @@ def main():
     elif args.workload == "c3":
         w = common.config3(n=n)
     else:
-        w = common.config5(n=n)
+        w = common.config5(n=64)   # the sweep generates its states in the kernel: only model / scene / params are used
     kind = "dragon" if w.model.has_gimbal else "hydrus"
     NL, P, M, J = w.model.n_rotor, w.model.n_prim, len(w.boxes), w.model.n_joint
-    if world > 1:
-        # every rank owns a different shard of the sweep: reseed the states per rank
+    if world > 1 and args.workload != "c5":
+        # every rank owns a different shard of the batch: reseed the states per rank
         rng = common.rng_for(100 + rank)
         w.soa[7:] = rng.uniform(-1.58, 1.58, (J, n))
 
     eng = mp.Engine(w.model, w.boxes, w.params, device=local_rank)
     eng.set_profiling(True)   # HIP events on the launch stream around each kernel of a call
-    d_soa = torch.from_numpy(w.soa).to(dev)
+    d_soa = torch.from_numpy(w.soa).to(dev)   # (c5: unused, the sweep reads no input)
     words = (n + 63) // 64
     d_mask = torch.zeros(words, dtype=torch.int64, device=dev)
     d_all = torch.zeros(world * words, dtype=torch.int64, device=dev) if world > 1 else None
     d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 
+    sweep = args.workload == "c5"   # config 5: states generated in the kernel from the sample index, rank r sweeps [r*n, (r+1)*n)
+    sweep_pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
+
+    def run_batch():
+        if sweep:
+            eng.sweep_mask_dev(sweep_pose, rank * n, n, common.SEED0 + 5, d_mask)
+        else:
+            eng.is_valid_mask_dev(d_soa, w.layout, d_mask)
+
     def step():
-        eng.is_valid_mask_dev(d_soa, w.layout, d_mask)
+        run_batch()
         if world > 1:
             dist.all_gather_into_tensor(d_all, d_mask)
             dist.all_reduce(d_cnt)
@@ -203,7 +212,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        eng.is_valid_mask_dev(d_soa, w.layout, d_mask)
+        run_batch()
         ev[k][1].record()
         if world > 1:
             dist.all_gather_into_tensor(d_all, d_mask)
@@ -217,7 +226,7 @@ def main():
     # per-kernel split of a call (library events on the same stream), sampled outside the timed region
     split = []
     for _ in range(min(args.steps, 10)):
-        eng.is_valid_mask_dev(d_soa, w.layout, d_mask)
+        run_batch()
         split.append(eng.last_kernel_ms())
     screen_ms = float(np.mean([x[0] for x in split]))
     exact_ms = float(np.mean([x[1] for x in split]))
@@ -232,7 +241,7 @@ def main():
         value = total / elapsed
         f_model = F_MODEL[(kind, NL)]
         f_alg = f_model + P * M * F_PAIR
-        b_alg = 8 * (7 + J) + 1.0 / 8.0
+        b_alg = (0 if sweep else 8 * (7 + J)) + 1.0 / 8.0
         ach_tflops = n * f_alg / (screen_ms * 1e-3) / 1e12
         pmc = pmc_traffic(args.workload)
         out = {
@@ -249,7 +258,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{w.name}: {kind.upper()} {NL}-link, joints+base, {n} samples/GPU, {M} box obstacles, "
-                                   f"{P} robot primitives, flags as packed mask",
+                                   f"{P} robot primitives, flags as packed mask" + (", states generated in-kernel (C-space sweep)" if sweep else ""),
                        "samples_per_gpu": n, "obstacles": M, "links": NL, "parallelism": f"shard{world}"},
             # the path is fp64-VALU bound (no dense contraction, ~100 B of HBM traffic per check), so
             # `bound` deviates from the hbm|mfma menu on purpose.  achieved = n * F_alg / t(screen_kernel), with

@@ -257,6 +257,20 @@ int mvk_is_valid_batch_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t l
 int mvk_is_valid_mask_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout,
                           uint64_t* d_mask, void* stream);
 
+/* C-space sweep (BASELINE config 5; the reference's manual joint-space validity sweep is
+ * sampling_based_method/scripts/state_validation_l4.py:46-68).  Sample i (i = first_index ..
+ * first_index + n - 1) has the fixed root pose `root_pose7` (px py pz qx qy qz qw) and joints
+ *   j = joint_low[j] + (joint_high[j] - joint_low[j]) * (u + 0.5) / 2^32,
+ *   u = philox4x32-10(counter = {lo32(i), hi32(i), j / 4, 0}, key = {lo32(seed), hi32(seed)})[j % 4]
+ * with the joint bounds of the ctx's params: the states are generated in the kernel from the
+ * sample index, no input is read (a 64 M-sample sweep sharded over 8 GPUs moves 8 MiB of mask).
+ * Bit i - first_index of d_mask is the verdict of sample i.  mvk_sweep_states materialises the
+ * same states on the host (SoA, MVK_LAYOUT_POSE7 rows; no device needed) for checking. */
+int mvk_sweep_mask_dev(mvk_ctx* ctx, const double* root_pose7, uint64_t first_index, size_t n, uint64_t seed,
+                       uint64_t* d_mask, void* stream);
+int mvk_sweep_states(const mvk_params* params, int n_joint, const double* root_pose7, uint64_t first_index,
+                     size_t n, uint64_t seed, double* soa, size_t ld);
+
 /* Full evaluation with per-sample model quantities (what MultilinkState /
  * addState expose: multilink_state.cpp:98-137, motion_planning.cpp:546-642). */
 int mvk_eval_batch(mvk_ctx* ctx, const double* soa, size_t n, size_t ld, int layout,

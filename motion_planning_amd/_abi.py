@@ -134,6 +134,8 @@ PROTOTYPES = {
     "mvk_is_valid_batch": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp]),
     "mvk_is_valid_batch_dev": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, vp]),
     "mvk_is_valid_mask_dev": (ip, [vp, vp, sz, sz, ip, vp, vp]),
+    "mvk_sweep_mask_dev": (ip, [vp, vp, C.c_uint64, sz, C.c_uint64, vp, vp]),
+    "mvk_sweep_states": (ip, [PP, ip, vp, C.c_uint64, sz, C.c_uint64, vp, sz]),
     "mvk_eval_batch": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, C.POINTER(DetailOut)]),
     "mvk_eval_batch_dev": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, C.POINTER(DetailOut), vp]),
     "mvk_reduce_stats": (ip, [vp, C.POINTER(Stats)]),

@@ -561,6 +561,52 @@ extern "C" int mvk_is_valid_mask_dev(mvk_ctx* c, const double* d_soa, size_t n, 
                       static_cast<hipStream_t>(stream));
 }
 
+extern "C" int mvk_sweep_mask_dev(mvk_ctx* c, const double* root_pose7, uint64_t first_index, size_t n, uint64_t seed,
+                                  uint64_t* d_mask, void* stream) {
+  if (!c || !root_pose7 || !d_mask) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  if (n == 0) return MVK_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  EvalArgs a;
+  base_args(c, a);
+  a.n = n;
+  a.ld = n;
+  a.layout = MVK_LAYOUT_POSE7;
+  a.mask = d_mask;
+  a.sweep_on = 1;
+  a.sweep_first = first_index;
+  a.sweep_seed = seed;
+  for (int k = 0; k < 7; ++k) a.sweep_pose[k] = root_pose7[k];
+  for (int j = 0; j < c->model.n_joint; ++j) {
+    a.sweep_lo[j] = c->params.joint_low[j];
+    a.sweep_span[j] = c->params.joint_high[j] - c->params.joint_low[j];
+  }
+  c->stats_valid = false;
+  if (int rc = prepare_queue(c, a, n)) return rc;
+  const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, static_cast<hipStream_t>(stream), c->profiling ? c->ev : nullptr);
+  c->timed = c->profiling;
+  if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+  return MVK_OK;
+}
+
+extern "C" int mvk_sweep_states(const mvk_params* prm, int J, const double* root_pose7, uint64_t first_index, size_t n,
+                                uint64_t seed, double* soa, size_t ld) {
+  if (!prm || !root_pose7 || (n && !soa) || ld < n || J < 0 || J > MVK_MAX_JOINT) return fail(MVK_ERR_INVALID_ARG, "mvk_sweep_states: bad argument");
+  for (size_t q = 0; q < n; ++q) {
+    const uint64_t i = first_index + q;
+    for (int r = 0; r < 7; ++r) soa[r * ld + q] = root_pose7[r];
+    for (int b = 0; b < (J + 3) / 4; ++b) {
+      uint32_t u[4];
+      philox4x32_10(static_cast<uint32_t>(i), static_cast<uint32_t>(i >> 32), static_cast<uint32_t>(b), 0u,
+                    static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), u);
+      for (int k = 0; k < 4 && 4 * b + k < J; ++k) {
+        const int j = 4 * b + k;
+        soa[(7 + j) * ld + q] = std::fma(prm->joint_high[j] - prm->joint_low[j], sweep_unit(u[k]), prm->joint_low[j]);
+      }
+    }
+  }
+  return MVK_OK;
+}
+
 extern "C" int mvk_eval_batch_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout,
                                   uint8_t* d_flags, double* d_min_dist, double* d_margin, uint8_t* d_band,
                                   const mvk_detail_out* d_detail, void* stream) {

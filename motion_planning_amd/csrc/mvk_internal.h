@@ -112,6 +112,11 @@ struct EvalArgs {
   uint32_t* queue_count_next;  // zeroed by this call for the next one
   // per-block partial statistics (full mode) or nullptr
   void* stats_partial;
+  // C-space sweep (mvk_sweep_mask_dev): states are generated from the sample index, nothing is read
+  int32_t sweep_on;
+  uint64_t sweep_first, sweep_seed;
+  double sweep_pose[7];
+  double sweep_lo[MVK_MAX_JOINT], sweep_span[MVK_MAX_JOINT];
   // collision-avoidance rows (avoid_kernel): parameters and nullable outputs, row pitch ld
   double av_gain, av_range, av_forbid;
   int32_t av_full_body;
@@ -145,6 +150,27 @@ int launch_edge_finish(const int32_t* first_invalid, const int32_t* nd, int32_t 
                        uint64_t n_edges, void* stream);
 int launch_stats_final(const StatsPartial* partial, uint64_t n_partial, StatsPartial* out, void* stream);
 bool kernel_supported(int robot_type, int n_links);
+
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): the counter-based
+// generator of the C-space sweep.  Shared by host and device code so that both produce the same states.
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define MVK_HD __host__ __device__ inline
+#else
+#define MVK_HD inline
+#endif
+MVK_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0, p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+    const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0, n1 = static_cast<uint32_t>(p1);
+    const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1, n3 = static_cast<uint32_t>(p0);
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// uniform in (0, 1) from 32 random bits, exactly representable steps of 2^-32
+MVK_HD double sweep_unit(uint32_t u) { return (static_cast<double>(u) + 0.5) * (1.0 / 4294967296.0); }
 
 // host OMPL arithmetic (mvk_space.cpp)
 int space_dim(const mvk_params* p, int n_joint);

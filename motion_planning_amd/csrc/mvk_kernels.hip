@@ -1144,6 +1144,23 @@ template <int NJ, bool EDGE, bool WANT_JOINTS>
 DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t& edge, int& step) {
   edge = 0;
   step = 0;
+  if (!EDGE && A.sweep_on) {
+    // C-space sweep: joint j of sample i = low_j + span_j * unit(philox(counter = {i, j / 4}, key = seed)[j % 4])
+#pragma unroll
+    for (int r = 0; r < 7; ++r) st[r] = A.sweep_pose[r];
+    const uint64_t i = A.sweep_first + li;
+#pragma unroll
+    for (int b = 0; b < (NJ + 3) / 4; ++b) {
+      uint32_t u[4] = {0, 0, 0, 0};
+      if (WANT_JOINTS)
+        philox4x32_10(static_cast<uint32_t>(i), static_cast<uint32_t>(i >> 32), static_cast<uint32_t>(b), 0u,
+                      static_cast<uint32_t>(A.sweep_seed), static_cast<uint32_t>(A.sweep_seed >> 32), u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (4 * b + k < NJ) st[7 + 4 * b + k] = WANT_JOINTS ? fma(A.sweep_span[4 * b + k], sweep_unit(u[k]), A.sweep_lo[4 * b + k]) : 0.0;
+    }
+    return;
+  }
   if (!EDGE) {
     const double* __restrict__ src = A.soa;
     if (A.layout == MVK_LAYOUT_POSE7) {

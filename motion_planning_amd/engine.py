@@ -83,6 +83,16 @@ def broadphase_query(boxes, radius, points, cap=256):
     return counts, ids
 
 
+def sweep_states(params, n_joint, root_pose7, first_index, n, seed):
+    """The states of the C-space sweep, materialised on the host ([7+J, n], POSE7 rows); no device needed."""
+    lib = A.load()
+    pose = np.ascontiguousarray(root_pose7, np.float64)
+    out = np.zeros((7 + n_joint, n))
+    _check(lib, lib.mvk_sweep_states(C.byref(params), n_joint, pose.ctypes.data_as(C.c_void_p), int(first_index), int(n),
+                                     int(seed), out.ctypes.data_as(C.c_void_p), n))
+    return out
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -272,6 +282,16 @@ class Engine:
         assert d_mask.numel() * 64 >= n
         _check(self.lib, self.lib.mvk_is_valid_mask_dev(self.ctx, self._dp(d_soa), n, ld, layout, self._dp(d_mask),
                                                         self._stream(stream)))
+
+    def sweep_mask_dev(self, root_pose7, first_index, n, seed, d_mask, stream=None):
+        """C-space sweep: states generated in the kernel from the sample index (include/mvk.h)."""
+        pose = np.ascontiguousarray(root_pose7, np.float64)
+        assert pose.shape == (7,) and d_mask.numel() * 64 >= n
+        _check(self.lib, self.lib.mvk_sweep_mask_dev(self.ctx, _ptr(pose), int(first_index), int(n), int(seed),
+                                                     self._dp(d_mask), self._stream(stream)))
+
+    def sweep_states(self, root_pose7, first_index, n, seed):
+        return sweep_states(self.params, self.n_joint, root_pose7, first_index, n, seed)
 
     def check_motion_batch_dev(self, d_s1, d_s2, nd, d_ok, d_first=None, stream=None):
         rows, E = d_s1.shape

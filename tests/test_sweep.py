@@ -1,0 +1,86 @@
+"""C-space sweep (BASELINE config 5): the counter-based state generator shared by host and device.
+
+Philox4x32-10 is checked against the published known-answer vector of Random123 (Salmon et al., SC'11) and
+against an independent numpy restatement; the GPU test checks that the in-kernel generator produces the
+verdicts of the materialised states."""
+import numpy as np
+import pytest
+
+import common
+import motion_planning_amd as mp
+from motion_planning_amd import _abi as A
+
+
+def philox_np(c, k):
+    """c: [n,4] uint32 counters, k: (k0, k1) -> [n,4] uint32 (numpy restatement, uint64 arithmetic)"""
+    c = c.astype(np.uint64).copy()
+    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
+    M = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[:, 0]
+        p1 = np.uint64(0xCD9E8D57) * c[:, 2]
+        c = np.stack([(p1 >> np.uint64(32)) ^ c[:, 1] ^ k0, p1 & M, (p0 >> np.uint64(32)) ^ c[:, 3] ^ k1, p0 & M], 1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M
+    return c.astype(np.uint32)
+
+
+def _raw_bits(J, first, n, seed):
+    model = mp.make_model("hydrus", 8)
+    p = mp.default_params(model, A.MODE_JOINTS_AND_BASE, A.SE3)
+    for j in range(J):
+        p.joint_low[j], p.joint_high[j] = 0.0, 4294967296.0    # joint value = u + 0.5
+    st = mp.sweep_states(p, J, [0, 0, 0, 0, 0, 0, 1], first, n, seed)
+    return (st[7:] - 0.5).astype(np.uint64).T       # [n, J]
+
+
+def test_philox_known_answer_and_numpy_restatement():
+    assert np.array_equal(philox_np(np.zeros((1, 4), np.uint32), (0, 0))[0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8])
+    assert np.array_equal(philox_np(np.full((1, 4), 0xFFFFFFFF, np.uint32), (0xFFFFFFFF, 0xFFFFFFFF))[0],
+                          [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD])
+    assert np.array_equal(philox_np(np.array([[0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], np.uint32), (0xA4093822, 0x299F31D0))[0],
+                          [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1])
+    # the library's generator: sample 0, seed 0 is the all-zero known-answer vector
+    assert np.array_equal(_raw_bits(4, 0, 1, 0)[0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8])
+    first, n, seed, J = (1 << 33) + 12345, 500, 0x5EED0005DEADBEEF, 7
+    got = _raw_bits(J, first, n, seed)
+    idx = first + np.arange(n, dtype=np.uint64)
+    for b in range(2):
+        c = np.stack([idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32), np.full(n, b, np.uint64), np.zeros(n, np.uint64)], 1)
+        ref = philox_np(c.astype(np.uint32), (seed & 0xFFFFFFFF, seed >> 32))
+        cols = min(4, J - 4 * b)
+        assert np.array_equal(got[:, 4 * b:4 * b + cols], ref[:, :cols])
+
+
+def test_sweep_states_cover_the_joint_box_uniformly():
+    model = mp.make_model("hydrus", 8)
+    p = mp.default_params(model, A.MODE_JOINTS_AND_BASE, A.SE3)
+    st = mp.sweep_states(p, 7, [0.1, 0.2, 0.3, 0, 0, 0, 1], 0, 200000, 5)
+    assert np.all(st[0] == 0.1) and np.all(st[6] == 1.0)
+    j = st[7:]
+    assert j.min() > -1.58 and j.max() < 1.58
+    assert np.all(np.abs(j.mean(1)) < 0.02) and np.all(np.abs(j.std(1) - 3.16 / np.sqrt(12)) < 0.01)
+    assert np.abs(np.corrcoef(j)[np.triu_indices(7, 1)]).max() < 0.01
+    # index ranges compose: a shard of the sweep is a slice of it
+    part = mp.sweep_states(p, 7, [0.1, 0.2, 0.3, 0, 0, 0, 1], 1000, 64, 5)
+    assert np.array_equal(part, st[:, 1000:1064])
+
+
+@pytest.mark.gpu
+def test_device_sweep_matches_materialised_states():
+    import torch
+    w = common.config5(n=8)
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    seed = 0x5EED0005
+    for first, n in ((0, 1 << 18), ((1 << 32) - 1000, 5000), (77, 63)):
+        words = (n + 63) // 64
+        mask = torch.zeros(words, dtype=torch.int64, device="cuda")
+        eng.sweep_mask_dev(pose, first, n, seed, mask)
+        torch.cuda.synchronize()
+        st = eng.sweep_states(pose, first, n, seed)
+        ref = eng.is_valid_batch(st, A.LAYOUT_POSE7)["flags"]
+        bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")[:n]
+        assert np.array_equal(bits, ref), (first, n)
+        assert 0 < ref.sum() < n or n < 100
+    eng.close()
