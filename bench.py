@@ -199,6 +199,7 @@ def main():
     def step():
         run_batch()
         if world > 1:
+            eng.mask_count_dev(d_mask, n, d_cnt)
             dist.all_gather_into_tensor(d_all, d_mask)
             dist.all_reduce(d_cnt)
 
@@ -215,6 +216,7 @@ def main():
         run_batch()
         ev[k][1].record()
         if world > 1:
+            eng.mask_count_dev(d_mask, n, d_cnt)
             dist.all_gather_into_tensor(d_all, d_mask)
             dist.all_reduce(d_cnt)
     torch.cuda.synchronize()

@@ -271,6 +271,10 @@ int mvk_sweep_mask_dev(mvk_ctx* ctx, const double* root_pose7, uint64_t first_in
 int mvk_sweep_states(const mvk_params* params, int n_joint, const double* root_pose7, uint64_t first_index,
                      size_t n, uint64_t seed, double* soa, size_t ld);
 
+/* number of valid samples among the first n_bits of a packed mask, written to *d_count (device):
+ * the scalar that is all-reduced across GPUs next to the mask all-gather */
+int mvk_mask_count_dev(const uint64_t* d_mask, size_t n_bits, uint64_t* d_count, void* stream);
+
 /* Full evaluation with per-sample model quantities (what MultilinkState /
  * addState expose: multilink_state.cpp:98-137, motion_planning.cpp:546-642). */
 int mvk_eval_batch(mvk_ctx* ctx, const double* soa, size_t n, size_t ld, int layout,

@@ -136,6 +136,7 @@ PROTOTYPES = {
     "mvk_is_valid_mask_dev": (ip, [vp, vp, sz, sz, ip, vp, vp]),
     "mvk_sweep_mask_dev": (ip, [vp, vp, C.c_uint64, sz, C.c_uint64, vp, vp]),
     "mvk_sweep_states": (ip, [PP, ip, vp, C.c_uint64, sz, C.c_uint64, vp, sz]),
+    "mvk_mask_count_dev": (ip, [vp, sz, vp, vp]),
     "mvk_eval_batch": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, C.POINTER(DetailOut)]),
     "mvk_eval_batch_dev": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, C.POINTER(DetailOut), vp]),
     "mvk_reduce_stats": (ip, [vp, C.POINTER(Stats)]),

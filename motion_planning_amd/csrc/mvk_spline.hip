@@ -73,6 +73,29 @@ spline_eval_kernel(const SplineDev S, const double* __restrict__ t, uint64_t nt,
   }
 }
 
+// number of set bits among the first n_bits of a packed validity mask, by one block (the masks are
+// n/8 bytes: a 64 M-sample sweep is 8 MiB)
+__global__ void __launch_bounds__(1024)
+mask_count_kernel(const unsigned long long* __restrict__ mask, uint64_t n_bits, unsigned long long* __restrict__ count) {
+  __shared__ unsigned long long part[16];
+  const uint64_t words = (n_bits + 63) / 64;
+  unsigned long long acc = 0;
+  for (uint64_t w = threadIdx.x; w < words; w += 1024) {
+    unsigned long long v = mask[w];
+    if (w == words - 1 && (n_bits & 63)) v &= (1ull << (n_bits & 63)) - 1ull;
+    acc += static_cast<unsigned long long>(__popcll(v));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tot = 0;
+    for (int k = 0; k < 16; ++k) tot += part[k];
+    *count = tot;
+  }
+}
+
 struct DeviceCopy {
   std::vector<double*> ctrl, knots;
 };
@@ -152,5 +175,16 @@ extern "C" int mvk_spline_eval_dev(mvk_spline* s, int device, const double* d_t,
                      d_t, static_cast<uint64_t>(nt), d_out, static_cast<uint64_t>(ld));
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "spline kernel launch failed: %s", hipGetErrorString(e));
+  return MVK_OK;
+}
+
+// valid count of a packed mask (the statistic that is all-reduced across GPUs next to the mask gather)
+extern "C" int mvk_mask_count_dev(const uint64_t* d_mask, size_t n_bits, uint64_t* d_count, void* stream) {
+  if (!d_mask || !d_count) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  hipLaunchKernelGGL(mask_count_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const unsigned long long*>(d_mask), static_cast<uint64_t>(n_bits),
+                     reinterpret_cast<unsigned long long*>(d_count));
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MVK_ERR_HIP, "mask count kernel launch failed: %s", hipGetErrorString(e));
   return MVK_OK;
 }

@@ -293,6 +293,9 @@ class Engine:
     def sweep_states(self, root_pose7, first_index, n, seed):
         return sweep_states(self.params, self.n_joint, root_pose7, first_index, n, seed)
 
+    def mask_count_dev(self, d_mask, n_bits, d_count, stream=None):
+        _check(self.lib, self.lib.mvk_mask_count_dev(self._dp(d_mask), int(n_bits), self._dp(d_count), self._stream(stream)))
+
     def check_motion_batch_dev(self, d_s1, d_s2, nd, d_ok, d_first=None, stream=None):
         rows, E = d_s1.shape
         ld = d_s1.stride(0)

@@ -82,5 +82,8 @@ def test_device_sweep_matches_materialised_states():
         ref = eng.is_valid_batch(st, A.LAYOUT_POSE7)["flags"]
         bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")[:n]
         assert np.array_equal(bits, ref), (first, n)
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        eng.mask_count_dev(mask, n, cnt)       # the scalar all-reduced next to the mask gather
+        assert int(cnt.item()) == int(ref.sum())
         assert 0 < ref.sum() < n or n < 100
     eng.close()
