@@ -279,7 +279,9 @@ def main():
                          "pmc_source": (pmc or {}).get("source")},
             "valid_in_first_4096_words": valid,
         }
-        if not args.no_cpu_baseline:
+        if world > 1:
+            out["valid_total_last_step"] = int(d_cnt.item())   # all-reduced over ranks (mvk_mask_count_dev + RCCL sum)
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w)
         if not args.no_planner and world == 1:
             out["rrt_connect"] = rrt_connect_gap_pass()
