@@ -131,13 +131,69 @@ def pmc_traffic(workload):
         return None
 
 
+def bench_edges(args, world, rank, local_rank, dev):
+    """config c4: batched MotionValidator edge checks (64 interpolation steps per edge), HYDRUS 6-link, sharded by
+    edge over the ranks (never by step); each step ends with the all-gather of the per-edge verdict bytes."""
+    import torch
+    import torch.distributed as dist
+
+    import common
+    import motion_planning_amd as mp
+    E = args.edges
+    model, params, boxes, s1, s2, nd = common.config4(n_edges=E)
+    if world > 1:   # every rank owns different edges
+        rng = common.rng_for(200 + rank)
+        s1[3:] = rng.uniform(-1.58, 1.58, s1[3:].shape)
+        s2[3:] = np.clip(s1[3:] + rng.normal(scale=0.05, size=s1[3:].shape), -1.58, 1.58)
+    eng = mp.Engine(model, boxes, params, device=local_rank)
+    d1, d2 = torch.from_numpy(s1).to(dev), torch.from_numpy(s2).to(dev)
+    ok = torch.zeros(E, dtype=torch.uint8, device=dev)
+    first = torch.zeros(E, dtype=torch.int32, device=dev)
+    ok_all = torch.zeros(world * E, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        eng.check_motion_batch_dev(d1, d2, nd, ok, first)
+        if world > 1:
+            dist.all_gather_into_tensor(ok_all, ok)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "state validity checks/sec", "value": world * E * nd * args.steps / elapsed, "unit": "checks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"c4: HYDRUS 6-link edge checks, {E} edges/GPU x {nd} interpolation steps, 100 box obstacles",
+                       "edges_per_gpu": E, "steps_per_edge": nd, "parallelism": f"shard{world} (by edge)"},
+            "edges_per_s": world * E * args.steps / elapsed, "valid_edge_fraction": float(ok.float().mean().item())}))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=1 << 20)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2se3", "c2k", "c3", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2se3", "c2k", "c3", "c4", "c5"])
+    ap.add_argument("--edges", type=int, default=1 << 16, help="c4: edges per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
     ap.add_argument("--no-edges", action="store_true")
@@ -161,6 +217,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "c4":
+        return bench_edges(args, world, rank, local_rank, dev)
     n = args.samples
     if args.workload == "c2":
         w = common.config2(n=n)
