@@ -21,6 +21,8 @@
 #include <cmath>
 #include <type_traits>
 
+#include <cstring>
+
 #include "mvk_internal.h"
 
 namespace mvk {
@@ -35,13 +37,33 @@ namespace {
 #endif
 
 // Diagnostic builds only (profiles/diag.py, -DMVK_PROF): event counters, one atomic per wave.
+#if defined(MVK_PROF) || defined(MVK_PROFT)
+__device__ unsigned long long g_prof[48];
+#endif
 #ifdef MVK_PROF
-__device__ unsigned long long g_prof[32];
 #define PROF_LANES(idx, pred) do { const unsigned long long b__ = __ballot(pred); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_prof[idx], (unsigned long long)__popcll(b__)); } while (0)
 #define PROF_WAVE(idx) do { if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_prof[idx], 1ull); } while (0)
 #else
 #define PROF_LANES(idx, pred) do { } while (0)
 #define PROF_WAVE(idx) do { } while (0)
+#endif
+#ifdef MVK_PROFT
+// stage clocks of the exact kernel (100 MHz wall clock): every wave writes its own record (no
+// atomics: same-address atomics from thousands of waves would be the thing measured); the host
+// reduces them in mvk_debug_prof
+constexpr int kProfWaves = 1 << 15;
+__device__ unsigned long long g_rec[kProfWaves * 8];
+#define PROF_T(var) const unsigned long long var = wall_clock64()
+#define PROF_STAGE_DECL unsigned long long prof_d[4] = {0, 0, 0, 0}
+#define PROF_STAGE(slot, t0, t1) prof_d[slot] += (t1) - (t0)
+#define PROF_STAGE_FLUSH do { const unsigned w__ = ((blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)); \
+    if ((threadIdx.x & 63) == 0 && w__ < kProfWaves) { unsigned long long* r__ = g_rec + 8 * w__; r__[0] = 1; r__[1] = t_entry; r__[2] = wall_clock64(); \
+      for (int i__ = 0; i__ < 4; ++i__) r__[3 + i__] = prof_d[i__]; } } while (0)
+#else
+#define PROF_T(var) do { } while (0)
+#define PROF_STAGE_DECL do { } while (0)
+#define PROF_STAGE(slot, t0, t1) do { } while (0)
+#define PROF_STAGE_FLUSH do { } while (0)
 #endif
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
@@ -335,6 +357,8 @@ struct Shape {
   static constexpr int kSeg = kGimbal ? 2 * NL - 1 : NL;
   static constexpr int kJoint = kGimbal ? 2 * (NL - 1) : NL - 1;
   static constexpr int kDof = kGimbal ? 3 : 4;
+  // rows of a queue record: root position and quaternion, cos/sin of every joint
+  static constexpr int kRec = 7 + 2 * kJoint;
   // joint axis of segment k (compile time): HYDRUS yaw chain; DRAGON pitch (odd) / yaw (even)
   static constexpr int axis(int k) { return kGimbal ? ((k & 1) ? 1 : 2) : 2; }
   static constexpr int joint(int k) { return k - 1; }
@@ -345,12 +369,13 @@ struct Shape {
 };
 
 constexpr int kListCap = 32;     // full path: per-lane narrowphase candidates per primitive
-constexpr int kPairCap = 12;     // flag path: per-lane fp64 candidates per primitive
+constexpr int kItemCap = 4 * kBlock;  // flag path: fp64 (state, box) pairs per block and primitive slot
 
 // LDS views.  The pointers carry the LDS address space explicitly so that every access is a
 // ds_read / ds_write (a generic pointer would go through flat instructions and aperture checks).
 typedef __attribute__((address_space(3))) double lds_double;
 typedef __attribute__((address_space(3))) unsigned short lds_ushort;
+typedef __attribute__((address_space(3))) unsigned lds_uint;
 struct Smem {
   // [2*J][kBlock] cos/sin of the planned joints, lane-contiguous
   lds_double* cs;
@@ -804,13 +829,13 @@ DEV void prims_f32(const EvalArgs& A, const mvk_model* __restrict__ M, const Dev
 // ------------------------------------------------------------------------
 // flag path, phase 1: fp32 screen of every (primitive, box) pair the grid lists
 // ------------------------------------------------------------------------
-// hit   : some pair is a certain collision            -> the state is decided (invalid)
-// maybe : some pair needs the exact fp64 test         -> undecided unless hit
-// neither                                            -> no contact, decided
+// hit     : some pair is a certain collision                 -> the state is decided (invalid)
+// segmask : bit k = a pair on segment k needs the fp64 test  -> undecided unless hit
+// neither                                                   -> no contact, decided
 template <int ROBOT, int NL>
 DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
                         const DevObsF* __restrict__ obsf, const double pos[3], const double Rw[9], const Smem& sm,
-                        bool live, bool& hit, bool& maybe) {
+                        bool live, bool& hit, unsigned& segmask) {
   using S = Shape<ROBOT, NL>;
   const int tid = threadIdx.x;
   const bool f32_safe = fmax(fabs(pos[0]), fmax(fabs(pos[1]), fabs(pos[2]))) + X->reach <= A.f32_range;
@@ -818,7 +843,7 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
 #pragma unroll
   for (int k = 0; k < 9; ++k) R[k] = Rw[k];
   p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
-  hit = false; maybe = false;
+  hit = false; segmask = 0u;
 #pragma unroll 1
   for (int k = 0; k < S::kSeg; ++k) {
     if (k > 0) advance_frame(M, sm, tid, k, R, p);
@@ -830,6 +855,7 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
     xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
     unsigned gb, ge;
     grid_cell(A.grid, sc, live && !hit, gb, ge);
+    bool maybe = false;
 #pragma unroll 1
     for (unsigned g = gb; __any(g < ge); ++g) {
       PROF_WAVE(5);
@@ -856,108 +882,35 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
         if (hit) ge = gb;  // decided: stop fetching
       }
     }
+    segmask |= (maybe ? 1u : 0u) << k;
     if (!__any(live && !hit)) break;
   }
   hit = hit && live;
-  maybe = maybe && live;
+  segmask = live ? segmask : 0u;
 }
 
 // ------------------------------------------------------------------------
-// flag path, phase 2: exact fp64 tests for the states phase 1 left undecided
+// flag path, phase 2: exact fp64 tests for the pairs phase 1 left undecided
 // ------------------------------------------------------------------------
-// Runs on lanes compacted over the block: `src` is the block slot of the state this
-// lane re-evaluates (its joint cos/sin are in LDS slot src), `tid` owns the lists.
-template <int ROBOT, int NL>
-DEV bool collide_exact(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
-                       const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf, const double pos[3],
-                       const double Rw[9], const Smem& sm, int src, bool live) {
-  using S = Shape<ROBOT, NL>;
-  const int tid = threadIdx.x;
-  const bool f32_safe = fmax(fabs(pos[0]), fmax(fabs(pos[1]), fabs(pos[2]))) + X->reach <= A.f32_range;
-  double R[9], p[3];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) R[k] = Rw[k];
-  p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
-  bool hit = false;
-#pragma unroll 1
-  for (int k = 0; k < S::kSeg; ++k) {
-    if (k > 0) advance_frame(M, sm, src, k, R, p);
-    const int pb = X->seg_prim_begin[k], np = X->seg_prim_begin[k + 1] - pb;
-    if (np == 0) continue;
-    PrimF32 Pf;
-    prims_f32<S::kGimbal>(A, M, X, pb, np, R, p, f32_safe, Pf);
-    double sc[3];
-    xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
-    unsigned gb, ge;
-    grid_cell(A.grid, sc, live && !hit, gb, ge);
-    // level 1: the pairs fp32 cannot clear go to per-primitive lists in LDS
-    int cnt[kSegPrimMax];
-#pragma unroll
-    for (int j = 0; j < kSegPrimMax; ++j) cnt[j] = 0;
-#pragma unroll 1
-    for (unsigned g = gb; __any(g < ge); ++g) {
-      PROF_WAVE(8);
-      if (g < ge) {
-        const uint2 w = *reinterpret_cast<const uint2*>(A.grid.items + static_cast<size_t>(g) * kGridGroup);
-        const unsigned ids[kGridGroup] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
-        DevObsF F[kGridGroup];
-#pragma unroll
-        for (int c = 0; c < kGridGroup; ++c) F[c] = obsf[ids[c] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[c]];
-#pragma unroll
-        for (int c = 0; c < kGridGroup; ++c) {
-#pragma unroll
-          for (int j = 0; j < kSegPrimMax; ++j) {
-            if (j < np) {
-              const float l2 = point_box_dist2_f32(F[c], Pf.x[j], Pf.y[j], Pf.z[j]);
-              if (ids[c] != kGridNone && l2 <= Pf.may2[j]) {
-                if (cnt[j] < kPairCap) sm.list[(j * kPairCap + cnt[j]) * kBlock + tid] = static_cast<unsigned short>(ids[c]);
-                ++cnt[j];
-              }
-            }
-          }
-        }
-      }
-    }
-    // level 2: exact centre test + narrowphase, one primitive (kind wave-uniform) at a time
-#pragma unroll
-    for (int j = 0; j < kSegPrimMax; ++j) {
-      if (j >= np) continue;
-      const bool overflow = cnt[j] > kPairCap;  // fall back to this cell's whole list
-      int todo = (live && !hit) ? (overflow ? static_cast<int>(ge - gb) * kGridGroup : cnt[j]) : 0;
-      if (!__any(todo > 0)) continue;
-      const int q = X->prim_order[pb + j];
-      const int type = M->prim_type[q];
-      double pc[3], PR[9];
-      prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
-      const double rb = X->prim_bound[q], rin = X->prim_inner[q];
-      const double rb2 = rb * rb, rin2 = rin * rin;
-      const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
-#pragma unroll 1
-      for (int e = 0; __any(e < todo); ++e) {
-        PROF_WAVE(9);
-        PROF_LANES(10, e < todo);
-        if (e < todo) {
-          const unsigned ob = overflow ? A.grid.items[static_cast<size_t>(gb) * kGridGroup + e]
-                                       : sm.list[(j * kPairCap + e) * kBlock + tid];
-          if (ob != kGridNone) {
-            const DevObs O = obs[ob];
-            double t[3];
-            to_box_frame(O, pc, t);
-            const double l2 = point_box_dist2(t, O.h);
-            bool h = l2 <= rin2;  // a ball inside the primitive already touches the box
+// exact contact test of primitive q riding on the segment frame (R, p) against one box
+template <bool GIMBAL>
+DEV bool exact_pair(const mvk_model* __restrict__ M, const DevExtras* __restrict__ X, int q, const double R[9],
+                    const double p[3], const DevObs& O) {
+  const int type = M->prim_type[q];
+  double pc[3], PR[9];
+  prim_pose<GIMBAL, true>(M, q, R, p, pc, PR);
+  const double rb = X->prim_bound[q], rin = X->prim_inner[q];
+  double t[3];
+  to_box_frame(O, pc, t);
+  const double l2 = point_box_dist2(t, O.h);
+  bool h = l2 <= rin * rin;  // a ball inside the primitive already touches the box
 #ifdef MVK_PROF
-            { const bool nw = !h && type != MVK_PRIM_SPHERE && l2 <= rb2; const unsigned long long b = __ballot(nw);
-              if (b && (threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { atomicAdd(&g_prof[11], 1ull); atomicAdd(&g_prof[12], (unsigned long long)__popcll(b)); } }
+  { const bool nw = !h && type != MVK_PRIM_SPHERE && l2 <= rb * rb; const unsigned long long b = __ballot(nw);
+    if (b && (threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { atomicAdd(&g_prof[11], 1ull); atomicAdd(&g_prof[12], (unsigned long long)__popcll(b)); } }
 #endif
-            if (!h && type != MVK_PRIM_SPHERE && l2 <= rb2) h = narrow<false>(type, PR, d0, d1, d2, O, t) <= 0.0;
-            if (h) { hit = true; todo = 0; }
-          }
-        }
-      }
-    }
-    if (!__any(live && !hit)) break;
-  }
-  return hit && live;
+  if (!h && type != MVK_PRIM_SPHERE && l2 <= rb * rb)
+    h = narrow<false>(type, PR, M->prim_dim[q][0], M->prim_dim[q][1], M->prim_dim[q][2], O, t) <= 0.0;
+  return h;
 }
 
 // ------------------------------------------------------------------------
@@ -1137,6 +1090,24 @@ DEV void unpack_ompl(const EvalArgs& A, const double* s, double* st) {
   }
 }
 
+// lane -> (edge, step) of an edge batch: step j in 1..nd tests interp(s1, s2, j/nd)
+DEV void edge_step(const EvalArgs& A, uint64_t li, uint64_t& edge, int& step, int& nd_e) {
+  if (A.nd == nullptr) {
+    nd_e = A.nd_uniform;
+    edge = li / static_cast<uint64_t>(nd_e);
+    step = static_cast<int>(li - edge * nd_e) + 1;
+  } else {
+    uint64_t lo = 0, hi = A.n_edges;  // largest e with edge_off[e] <= li
+    while (hi - lo > 1) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (static_cast<uint64_t>(A.edge_off[mid]) <= li) lo = mid; else hi = mid;
+    }
+    edge = lo;
+    nd_e = A.nd[edge] < 1 ? 1 : A.nd[edge];
+    step = static_cast<int>(li - static_cast<uint64_t>(A.edge_off[edge])) + 1;
+  }
+}
+
 // State of global lane index li: a SoA batch row set, or step j of edge e densified in place
 // (lane -> (edge, step): step j in 1..nd tests interp(s1, s2, j/nd); j = nd is s2 itself).
 // WANT_JOINTS = false skips the joint rows (phase 2 of the flag path only needs the root pose).
@@ -1188,20 +1159,7 @@ DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t
     }
   } else {
     int nd_e;
-    if (A.nd == nullptr) {
-      nd_e = A.nd_uniform;
-      edge = li / static_cast<uint64_t>(nd_e);
-      step = static_cast<int>(li - edge * nd_e) + 1;
-    } else {
-      uint64_t lo = 0, hi = A.n_edges;  // largest e with edge_off[e] <= li
-      while (hi - lo > 1) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (static_cast<uint64_t>(A.edge_off[mid]) <= li) lo = mid; else hi = mid;
-      }
-      edge = lo;
-      nd_e = A.nd[edge] < 1 ? 1 : A.nd[edge];
-      step = static_cast<int>(li - static_cast<uint64_t>(A.edge_off[edge])) + 1;
-    }
+    edge_step(A, li, edge, step, nd_e);
     const double t = static_cast<double>(step) / static_cast<double>(nd_e);
     const bool last = step == nd_e;
     const int nb = (A.planning_mode == MVK_MODE_ONLY_JOINTS) ? 0 : (A.motion_type == MVK_SE2 ? 3 : 7);
@@ -1240,10 +1198,12 @@ DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t
 // Flag path = two launches on one stream.
 //   screen_kernel : one lane per state.  Walk 1 (model update, stability) and the fp32 screen of
 //                   the collision pairs.  Writes every output; a state the screen cannot decide
-//                   is written as "valid so far" and its index is appended to the ctx's queue.
-//   exact_kernel  : one lane per queue entry (dense waves instead of the few undecided lanes of
-//                   every wave).  Exact fp64 tests; a collision clears the state's flag / mask bit
-//                   (or lowers first_invalid of its edge).
+//                   is written as "valid so far" and its index is appended to the queue of every
+//                   chain segment that holds an undecided pair.
+//   exact_kernel  : every block takes chunks of one segment's queue, one lane per entry (dense
+//                   waves, the segment block-uniform, and a lane's serial work is one segment
+//                   instead of the whole chain).  Exact fp64 tests; a collision clears the state's flag / mask
+//                   bit (or lowers first_invalid of its edge).
 // Full path = full_kernel: exact minimum distance, margins, details and statistics, no early exit.
 template <int ROBOT, int NL, bool EDGE>
 __global__ void __launch_bounds__(kBlock, (Shape<ROBOT, NL>::kScreenWaves))
@@ -1257,12 +1217,19 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
   const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool in_range = gi < A.n;
   const uint64_t li = in_range ? gi : (A.n - 1);  // clamp: out-of-range lanes redo the last state
-  if (gi == 0) *A.queue_count_next = 0u;          // the counter the NEXT call on this ctx appends to
+  // the counters the NEXT call on this ctx appends to
+  if (gi < static_cast<uint64_t>(S::kSeg)) A.queue_count_next[gi * kQueueCounterPitch] = 0u;
 
   double st[7 + NJ];
   uint64_t edge;
   int step;
   fetch_state<NJ, EDGE, true>(A, li, st, edge, step);
+  // the root pose stays in LDS for the records of the undecided states (its registers are
+  // long dead by then; the joints' cos/sin are in sm.cs already)
+  __shared__ double sm_pose_[7 * kBlock];
+  lds_double* sm_pose = (lds_double*)sm_pose_;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) sm_pose[r * kBlock + threadIdx.x] = st[r];
 
   StateOut o;
   double Rw[9];
@@ -1271,30 +1238,84 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
 
   // lanes whose verdict cannot change any more (unstable, or not finite) generate no work
   const bool live = finite && A.do_coll && A.n_obs > 0 && (!A.do_stab || o.stable);
-  bool hit = false, maybe = false;
-  if (__any(live)) collide_screen<ROBOT, NL>(A, M, X, obsf, st, Rw, sm, live, hit, maybe);
-  const bool undecided = in_range && live && !hit && maybe;
-  PROF_LANES(0, true); PROF_LANES(1, live); PROF_LANES(2, hit); PROF_LANES(3, undecided); PROF_LANES(4, live && !hit && !maybe);
+  bool hit = false;
+  unsigned segmask = 0u;
+  if (__any(live)) collide_screen<ROBOT, NL>(A, M, X, obsf, st, Rw, sm, live, hit, segmask);
+  const bool undecided = in_range && live && !hit && segmask != 0u;
+  PROF_LANES(0, true); PROF_LANES(1, live); PROF_LANES(2, hit); PROF_LANES(3, undecided); PROF_LANES(4, live && !hit && segmask == 0u);
 
-  // append the undecided states of this block to the queue: one atomic per block
+  // append this block's undecided (state, segment) pairs to the segments' queues: one atomic per
+  // segment and block, issued by S::kSeg lanes at once
   {
-    __shared__ unsigned sm_wave_cnt[kBlock / 64];
-    __shared__ unsigned sm_base;
-    const unsigned long long bal = __ballot(undecided);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) sm_wave_cnt[wv] = static_cast<unsigned>(__popcll(bal));
-    __syncthreads();
-    unsigned before = 0, total = 0;
+    constexpr int kRec = S::kRec;
+    __shared__ unsigned sm_cnt[kBlock / 64][S::kSeg];
+    __shared__ unsigned sm_base[S::kSeg];
+    const unsigned todo = undecided ? segmask : 0u;
+    if (__syncthreads_or(todo != 0u)) {
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) {
-      const unsigned c = sm_wave_cnt[w];
-      before += (w < wv) ? c : 0u;
-      total += c;
-    }
-    if (total > 0) {  // block-uniform
-      if (threadIdx.x == 0) sm_base = atomicAdd(A.queue_count, total);
+      for (int k = 0; k < S::kSeg; ++k) {
+        const unsigned long long bal = __ballot((todo >> k) & 1u);
+        if (lane == 0) sm_cnt[wv][k] = static_cast<unsigned>(__popcll(bal));
+      }
       __syncthreads();
-      if (undecided) A.queue[sm_base + before + __popcll(bal & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(gi);
+      if (threadIdx.x < S::kSeg) {
+        unsigned total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) total += sm_cnt[w][threadIdx.x];
+        sm_base[threadIdx.x] = total ? atomicAdd(A.queue_count + threadIdx.x * kQueueCounterPitch, total) : 0u;
+      }
+      __syncthreads();
+      // Entry-major write-out: a wave holds a handful of entries spread over its lanes and the
+      // segments.  They are listed in LDS (segment-major, so neighbours share a queue and sit in
+      // consecutive slots), then lane e writes entry e: its index and its record, row by row, from
+      // the pose / cos-sin rows of the source lane.  One coalesced store sequence per wave instead
+      // of one sparse sequence per (wave, segment).
+      __shared__ unsigned sm_ent_slot[kBlock / 64][64];
+      __shared__ unsigned short sm_ent_src[kBlock / 64][64];
+      unsigned pos[S::kSeg];
+      unsigned n_ent = 0;
+#pragma unroll
+      for (int k = 0; k < S::kSeg; ++k) {
+        const unsigned long long bal = __ballot((todo >> k) & 1u);
+        pos[k] = n_ent + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)));
+        n_ent += static_cast<unsigned>(__popcll(bal));
+      }
+      const uint64_t block_first = static_cast<uint64_t>(blockIdx.x) * kBlock;
+#pragma unroll 1
+      for (unsigned chunk = 0; chunk < n_ent; chunk += 64) {  // wave-uniform; one pass unless most lanes are undecided
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < S::kSeg; ++k) {
+          if (((todo >> k) & 1u) && pos[k] - chunk < 64u) {
+            unsigned before = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) before += (w < wv) ? sm_cnt[w][k] : 0u;
+            // rank within the segment's share of this wave = pos[k] - (entries of earlier segments)
+            unsigned earlier = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < S::kSeg; ++k2) earlier += (k2 < k) ? sm_cnt[wv][k2] : 0u;
+            sm_ent_slot[wv][pos[k] - chunk] = sm_base[k] + before + (pos[k] - earlier);
+            sm_ent_src[wv][pos[k] - chunk] = static_cast<unsigned short>((k << 8) | threadIdx.x);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (chunk + lane < n_ent) {
+          const unsigned slot = sm_ent_slot[wv][lane];
+          const unsigned src = sm_ent_src[wv][lane] & 0xFFu, k = sm_ent_src[wv][lane] >> 8;
+          A.queue[static_cast<uint64_t>(k) * A.queue_stride + slot] = static_cast<uint32_t>(block_first + src);
+          if (slot < A.queue_rec_cap) {
+            double* __restrict__ dst = A.queue_rec + static_cast<uint64_t>(k) * kRec * A.queue_rec_cap + slot;
+#pragma unroll
+            for (int r = 0; r < 7; ++r) dst[static_cast<uint64_t>(r) * A.queue_rec_cap] = sm_pose[r * kBlock + src];
+#pragma unroll
+            for (int r = 0; r < 2 * NJ; ++r)  // the frame of segment k turns on joints 0 .. k-1 only
+              if (r < 2 * static_cast<int>(k)) dst[static_cast<uint64_t>(7 + r) * A.queue_rec_cap] = sm.cs[r * kBlock + src];
+          }
+        }
+      }
     }
   }
 
@@ -1321,38 +1342,177 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
              const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf) {
   using S = Shape<ROBOT, NL>;
   constexpr int NJ = S::kJoint;
-  __shared__ double sm_cs[2 * NJ * kBlock];
-  __shared__ unsigned short sm_list[kSegPrimMax * kPairCap * kBlock];
-  Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list};
-  const unsigned count = *A.queue_count;  // written by screen_kernel, the launch before on this stream
-  for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kBlock; base < count; base += static_cast<uint64_t>(gridDim.x) * kBlock) {
-    const uint64_t qi = base + threadIdx.x;
-    const bool mine = qi < count;
-    const uint64_t gi = A.queue[mine ? qi : (count - 1)];
-    double st[7 + NJ], Rw[9];
-    uint64_t edge;
-    int step;
-    fetch_state<NJ, EDGE, true>(A, gi, st, edge, step);
-    quat_to_mat(st[3], st[4], st[5], st[6], Rw);
+  // LDS: the joint cos/sin of the frame walk and, once every lane has its frame, the block's pair
+  // list share one region; then the frames [12][kBlock], the list lengths and the verdict bytes
+  constexpr size_t kCsBytes = sizeof(double) * 2 * NJ * kBlock, kItemBytes = sizeof(unsigned) * kSegPrimMax * kItemCap;
+  __shared__ __align__(16) unsigned char sm_a[kCsBytes > kItemBytes ? kCsBytes : kItemBytes];
+  __shared__ double sm_frame_[12 * kBlock];
+  __shared__ unsigned sm_nitems[kSegPrimMax];
+  __shared__ unsigned char sm_hit[kBlock];
+  Smem sm{(lds_double*)sm_a, nullptr};
+  lds_uint* items = (lds_uint*)sm_a;
+  lds_double* frames = (lds_double*)sm_frame_;
+  const int tid = threadIdx.x, lane = threadIdx.x & 63;
+
+  PROF_T(t_entry);
+  PROF_STAGE_DECL;
+  // the segments' queues laid end to end in chunks of one block; the grid strides over the chunks
+  unsigned first[S::kSeg + 1];  // written by screen_kernel, the launch before on this stream
+  first[0] = 0;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      double sj, cj;
-      sincos_cw(st[7 + j], sj, cj);
-      sm.cs[(2 * j) * kBlock + threadIdx.x] = cj;
-      sm.cs[(2 * j + 1) * kBlock + threadIdx.x] = sj;
+  for (int k = 0; k < S::kSeg; ++k) first[k + 1] = first[k] + (A.queue_count[k * kQueueCounterPitch] + kBlock - 1) / kBlock;
+  for (unsigned chunk = blockIdx.x; chunk < first[S::kSeg]; chunk += gridDim.x) {
+    int ks = 0;  // the chain segment this chunk belongs to (block-uniform)
+#pragma unroll
+    for (int k = 1; k < S::kSeg; ++k) ks = (chunk >= first[k]) ? k : ks;
+    const unsigned count = A.queue_count[ks * kQueueCounterPitch];
+    const uint32_t* __restrict__ queue = A.queue + static_cast<uint64_t>(ks) * A.queue_stride;
+    const int pb = X->seg_prim_begin[ks], np = X->seg_prim_begin[ks + 1] - pb;
+    unsigned chunk_first = 0;
+#pragma unroll
+    for (int k = 1; k < S::kSeg; ++k) chunk_first = (ks == k) ? first[k] : chunk_first;
+    const uint64_t base = static_cast<uint64_t>(chunk - chunk_first) * kBlock;
+    const uint64_t qi = base + tid;
+    const bool mine = qi < count;
+    const uint64_t gi = queue[mine ? qi : (count - 1)];
+    PROF_T(t_q);
+    PROF_STAGE(0, t_entry, t_q);
+    double st[7 + NJ], R[9], p[3];
+    if (tid < kSegPrimMax) sm_nitems[tid] = 0u;
+    sm_hit[tid] = 0;
+    if (base < A.queue_rec_cap) {  // block-uniform: the screen stage left a record
+      const double* __restrict__ rec = A.queue_rec + static_cast<uint64_t>(ks) * S::kRec * A.queue_rec_cap + (mine ? qi : (count - 1));
+#pragma unroll
+      for (int r = 0; r < 7; ++r) st[r] = rec[static_cast<uint64_t>(r) * A.queue_rec_cap];
+#pragma unroll
+      for (int r = 0; r < 2 * NJ; ++r)
+        if (r < 2 * ks) sm.cs[r * kBlock + tid] = rec[static_cast<uint64_t>(7 + r) * A.queue_rec_cap];
+    } else {
+      uint64_t edge;
+      int step;
+      fetch_state<NJ, EDGE, true>(A, gi, st, edge, step);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        double sj, cj;
+        sincos_cw(st[7 + j], sj, cj);
+        sm.cs[(2 * j) * kBlock + tid] = cj;
+        sm.cs[(2 * j + 1) * kBlock + tid] = sj;
+      }
     }
+    quat_to_mat(st[3], st[4], st[5], st[6], R);
+    p[0] = st[0]; p[1] = st[1]; p[2] = st[2];
     PROF_WAVE(15);
-    const bool hit = collide_exact<ROBOT, NL>(A, M, X, obs, obsf, st, Rw, sm, threadIdx.x, mine);
+    // ---- the frame of segment ks ------------------------------------------------------------
+#pragma unroll 1
+    for (int k = 1; k <= ks; ++k) advance_frame(M, sm, tid, k, R, p);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) frames[e * kBlock + tid] = R[e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) frames[(9 + e) * kBlock + tid] = p[e];
+    __syncthreads();  // the cos/sin region is dead from here on: it becomes the pair list
+    PROF_T(t_fk);
+    PROF_STAGE(1, t_q, t_fk);
+
+    // ---- level 1: the fp32 screen again; the pairs it cannot clear go to the BLOCK's list --------
+    // (a lane's serial work would be its own longest list; shared out, it is the block's mean)
+    const bool f32_safe = fmax(fabs(st[0]), fmax(fabs(st[1]), fabs(st[2]))) + X->reach <= A.f32_range;
+    PrimF32 Pf;
+    prims_f32<S::kGimbal>(A, M, X, pb, np, R, p, f32_safe, Pf);
+    double sc[3];
+    xform(R, p, X->seg_sph[ks][0], X->seg_sph[ks][1], X->seg_sph[ks][2], sc);
+    unsigned gb, ge;
+    grid_cell(A.grid, sc, mine, gb, ge);
+    bool spilled = false;  // some pair of this lane did not fit the block's list
+#pragma unroll 1
+    for (unsigned g = gb; __any(g < ge); ++g) {
+      PROF_WAVE(8);
+      if (g < ge) {
+        const uint2 w = *reinterpret_cast<const uint2*>(A.grid.items + static_cast<size_t>(g) * kGridGroup);
+        const unsigned ids[kGridGroup] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+        DevObsF F[kGridGroup];
+#pragma unroll
+        for (int c = 0; c < kGridGroup; ++c) F[c] = obsf[ids[c] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[c]];
+#pragma unroll
+        for (int c = 0; c < kGridGroup; ++c) {
+#pragma unroll
+          for (int j = 0; j < kSegPrimMax; ++j) {
+            if (j < np) {
+              const float l2 = point_box_dist2_f32(F[c], Pf.x[j], Pf.y[j], Pf.z[j]);
+              const bool pass = ids[c] != kGridNone && l2 <= Pf.may2[j];
+              const unsigned long long bal = __ballot(pass);
+              if (bal) {  // one LDS atomic per wave and (candidate, primitive)
+                const int leader = __ffsll(static_cast<long long>(bal)) - 1;
+                unsigned at = 0;
+                if (lane == leader) at = atomicAdd(&sm_nitems[j], static_cast<unsigned>(__popcll(bal)));
+                at = __shfl(at, leader) + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)));
+                if (pass) {
+                  if (at < static_cast<unsigned>(kItemCap)) items[j * kItemCap + at] = (static_cast<unsigned>(tid) << 16) | ids[c];
+                  else spilled = true;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    PROF_T(t_l1);
+    PROF_STAGE(2, t_fk, t_l1);
+
+    // ---- level 2: exact tests, one pair per lane, primitive kind wave-uniform ---------------------
+#pragma unroll
+    for (int j = 0; j < kSegPrimMax; ++j) {
+      if (j >= np) continue;
+      const int q = X->prim_order[pb + j];
+      const unsigned total = min(sm_nitems[j], static_cast<unsigned>(kItemCap));
+#pragma unroll 1
+      for (unsigned i = tid; i < total; i += kBlock) {
+        PROF_WAVE(9);
+        PROF_LANES(10, true);
+        const unsigned it = items[j * kItemCap + i];
+        const unsigned src = it >> 16;
+        double Rs[9], ps[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Rs[e] = frames[e * kBlock + src];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) ps[e] = frames[(9 + e) * kBlock + src];
+        if (exact_pair<S::kGimbal>(M, X, q, Rs, ps, obs[it & 0xFFFFu])) sm_hit[src] = 1;
+      }
+    }
+    // a lane whose pairs did not all fit tests its whole cell list itself (scenes far denser than
+    // the list is sized for)
+    if (__any(spilled)) {
+#pragma unroll 1
+      for (int j = 0; j < np; ++j) {
+        const int q = X->prim_order[pb + j];
+        const unsigned todo = spilled ? (ge - gb) * kGridGroup : 0u;
+#pragma unroll 1
+        for (unsigned e = 0; __any(e < todo); ++e) {
+          if (e < todo) {
+            const unsigned ob = A.grid.items[static_cast<size_t>(gb) * kGridGroup + e];
+            if (ob != kGridNone && exact_pair<S::kGimbal>(M, X, q, R, p, obs[ob])) sm_hit[tid] = 1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    PROF_T(t_l2);
+    PROF_STAGE(3, t_l1, t_l2);
+    const bool hit = mine && sm_hit[tid] != 0;
     PROF_LANES(13, hit);
     if (hit) {  // the screen wrote this state as valid-so-far
       if (!EDGE) {
         if (A.flags) A.flags[gi] = 0;
         if (A.mask) atomicAnd(reinterpret_cast<unsigned long long*>(A.mask) + (gi >> 6), ~(1ull << (gi & 63)));
       } else {
+        uint64_t edge;
+        int step, nd_e;
+        edge_step(A, gi, edge, step, nd_e);
         atomicMin(&A.first_invalid[edge], step);
       }
     }
   }
+  if (blockIdx.x < first[S::kSeg]) PROF_STAGE_FLUSH;
 }
 
 template <int ROBOT, int NL>
@@ -1671,8 +1831,9 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s, hipEvent_t* e
     if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
     return hipGetLastError();
   }
-  // exact stage: grid-stride over the queue; a few blocks per CU are enough to drain it
-  dim3 g2(static_cast<unsigned>(blocks < 1024 ? blocks : 1024));
+  // exact stage: as many blocks as the chip holds at once stride over the chunks of all queues
+  const uint64_t chunks_max = blocks * Shape<ROBOT, NL>::kSeg, resident = a.exact_blocks ? a.exact_blocks : 768;
+  dim3 g2(static_cast<unsigned>(chunks_max < resident ? chunks_max : resident));
   if (edge_mode) {
     hipLaunchKernelGGL((screen_kernel<ROBOT, NL, true>), g, b, 0, s, a, a.model, a.extras, a.obsf);
     if (ev) (void)hipEventRecord(ev[1], s);
@@ -1688,10 +1849,29 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s, hipEvent_t* e
 
 }  // namespace
 
-#ifdef MVK_PROF
+#if defined(MVK_PROF) || defined(MVK_PROFT)
 extern "C" int mvk_debug_prof(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1; }
+#ifdef MVK_PROFT
+  {
+    static unsigned long long rec[kProfWaves * 8];
+    if (hipMemcpyFromSymbol(rec, HIP_SYMBOL(g_rec), sizeof(rec)) != hipSuccess) return -1;
+    if (out) {
+      unsigned long long first = ~0ull, last = 0;
+      for (int w = 0; w < kProfWaves; ++w) {
+        const unsigned long long* r = rec + 8 * w;
+        if (!r[0]) continue;
+        out[15] += 1;
+        first = r[1] < first ? r[1] : first;
+        last = r[2] > last ? r[2] : last;
+        for (int i = 0; i < 4; ++i) { out[16 + 2 * i] += r[3 + i]; if (r[3 + i] > out[17 + 2 * i]) out[17 + 2 * i] = r[3 + i]; }
+      }
+      out[40] = first; out[41] = last;
+    }
+    if (reset) { std::memset(rec, 0, sizeof(rec)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_rec), rec, sizeof(rec)) != hipSuccess) return -1; }
+  }
+#endif
+  if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
 #endif

@@ -39,14 +39,22 @@ def prof_counters(w, d, mask):
     lib = mp.abi.load()
     if not hasattr(lib, "mvk_debug_prof"):
         return
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 48)()
     eng = mp.Engine(w.model, w.boxes, w.params)
+    for _ in range(3):  # warm: buffers allocated and touched, code resident
+        eng.is_valid_mask_dev(d, w.layout, mask)
+    torch.cuda.synchronize()
     lib.mvk_debug_prof(None, 1)
     eng.is_valid_mask_dev(d, w.layout, mask)
     torch.cuda.synchronize()
     lib.mvk_debug_prof(buf, 1)
     eng.close()
     print("   counters: " + ", ".join(f"{PROF_NAMES[k]}={buf[k]}" for k in sorted(PROF_NAMES)), flush=True)
+    waves = max(int(buf[15]), 1)
+    stages = ["entry->queue", "fetch+frame", "level 1", "level 2"]
+    print("   exact_kernel stage clocks (us, mean over waves / max): " +
+          ", ".join(f"{nm} {buf[16 + 2 * i] / waves / 100:.2f}/{buf[17 + 2 * i] / 100:.2f}" for i, nm in enumerate(stages)) +
+          f"; first entry -> last exit {(buf[41] - buf[40]) / 100:.2f}, waves {waves}", flush=True)
 
 
 def main():
