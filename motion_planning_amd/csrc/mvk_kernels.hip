@@ -376,6 +376,7 @@ constexpr int kItemCap = 4 * kBlock;  // flag path: fp64 (state, box) pairs per 
 typedef __attribute__((address_space(3))) double lds_double;
 typedef __attribute__((address_space(3))) unsigned short lds_ushort;
 typedef __attribute__((address_space(3))) unsigned lds_uint;
+typedef __attribute__((address_space(3))) float lds_float;
 struct Smem {
   // [2*J][kBlock] cos/sin of the planned joints, lane-contiguous
   lds_double* cs;
@@ -832,61 +833,158 @@ DEV void prims_f32(const EvalArgs& A, const mvk_model* __restrict__ M, const Dev
 // hit     : some pair is a certain collision                 -> the state is decided (invalid)
 // segmask : bit k = a pair on segment k needs the fp64 test  -> undecided unless hit
 // neither                                                   -> no contact, decided
+//
+// Most (state, segment) pairs have an empty candidate list, so a loop over a lane's own list
+// would run with a quarter of the wave's lanes.  Instead every lane PUSHES its non-empty
+// (segment, list) as a work item into the wave's ring in LDS, and whenever a full wave of items is
+// waiting the wave POPS them one per lane: every lane tests one group of kGridGroup boxes of some
+// lane's segment, ORs the verdict into that lane's result word and pushes the rest of the list
+// back.  Items of a state already known to collide are dropped.
+constexpr int kRing = 128;       // items per wave: < 64 waiting + at most 64 pushed by one segment
+constexpr int kRingWords = 3 * kSegPrimMax + 3;  // primitive centres, first group, end group, tag
+constexpr unsigned kResHit = 0x80000000u;
+
+struct ScreenLds {
+  lds_uint* ring;      // this wave's items, [kRingWords][kRing]
+  lds_uint* res;       // this wave's result words, [64]: kResHit | maybe bits per segment
+  lds_float* thr;      // [segment][slot][2]: squared centre distances (certain hit, possible contact)
+};
+
+// screen thresholds of the primitive in slot j of segment k (see PrimF32 above)
+DEV void screen_thresholds(const EvalArgs& A, const DevExtras* __restrict__ X, int k, int j, float& hit2, float& may2) {
+  const int pb = X->seg_prim_begin[k], np = X->seg_prim_begin[k + 1] - pb;
+  hit2 = -1.0f;
+  may2 = -1.0f;
+  if (j < np) {
+    const int q = X->prim_order[pb + j];
+    const float rin = static_cast<float>(X->prim_inner[q]) * 0.999999f - A.f32_delta;
+    const float rb = (static_cast<float>(X->prim_bound[q]) + A.f32_delta) * 1.000001f;
+    hit2 = rin > 0.0f ? rin * rin : -1.0f;
+    may2 = rb * rb;
+  }
+}
+
+// one pop: lane i takes item head+i, tests one group, pushes the remainder
+DEV void screen_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const ScreenLds& L, unsigned& head, unsigned& qn) {
+  const int lane = threadIdx.x & 63;
+  const unsigned m = qn < 64u ? qn : 64u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  PROF_WAVE(5);
+  const bool active = static_cast<unsigned>(lane) < m;
+  const unsigned at = (head + lane) & (kRing - 1);
+  unsigned g = 0, gend = 0, tag = 0;
+  float c[3 * kSegPrimMax];
+  if (active) {
+    g = L.ring[(3 * kSegPrimMax) * kRing + at];
+    gend = L.ring[(3 * kSegPrimMax + 1) * kRing + at];
+    tag = L.ring[(3 * kSegPrimMax + 2) * kRing + at];
+#pragma unroll
+    for (int e = 0; e < 3 * kSegPrimMax; ++e) c[e] = __uint_as_float(L.ring[e * kRing + at]);
+  }
+  const unsigned src = tag & 63u, k = (tag >> 6) & 15u;
+  const bool safe = (tag >> 10) & 1u;
+  const unsigned np = tag >> 11;
+  bool work = active && !(__hip_atomic_load(L.res + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) & kResHit);
+  PROF_LANES(6, work);
+  bool more = false;
+  if (work) {
+    const uint2 w = *reinterpret_cast<const uint2*>(A.grid.items + static_cast<size_t>(g) * kGridGroup);
+    const unsigned ids[kGridGroup] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+    DevObsF F[kGridGroup];
+#pragma unroll
+    for (int e = 0; e < kGridGroup; ++e) F[e] = obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]];
+    bool hit = false, maybe = false;
+#pragma unroll
+    for (int j = 0; j < kSegPrimMax; ++j) {
+      if (!__any(static_cast<unsigned>(j) < np)) break;
+      float hit2 = L.thr[(k * kSegPrimMax + j) * 2], may2 = L.thr[(k * kSegPrimMax + j) * 2 + 1];
+      if (!safe) { hit2 = -1.0f; may2 = may2 < 0.0f ? -1.0f : INFINITY; }  // outside the fp32 range nothing is decided here
+#pragma unroll
+      for (int e = 0; e < kGridGroup; ++e) {
+        const float l2 = point_box_dist2_f32(F[e], c[3 * j], c[3 * j + 1], c[3 * j + 2]);
+        const bool real = ids[e] != kGridNone;
+        hit = hit || (real && l2 <= hit2);
+        maybe = maybe || (real && l2 <= may2);
+      }
+    }
+    if (hit) __hip_atomic_fetch_or(L.res + src, kResHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else if (maybe) __hip_atomic_fetch_or(L.res + src, 1u << k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    more = !hit && g + 1 < gend;
+  }
+  head = (head + m) & (kRing - 1);
+  qn -= m;
+  const unsigned long long bal = __ballot(more);
+  if (bal) {
+    const unsigned to = (head + qn + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)))) & (kRing - 1);
+    if (more) {
+#pragma unroll
+      for (int e = 0; e < 3 * kSegPrimMax; ++e) L.ring[e * kRing + to] = __float_as_uint(c[e]);
+      L.ring[(3 * kSegPrimMax) * kRing + to] = g + 1;
+      L.ring[(3 * kSegPrimMax + 1) * kRing + to] = gend;
+      L.ring[(3 * kSegPrimMax + 2) * kRing + to] = tag;
+    }
+    qn += static_cast<unsigned>(__popcll(bal));
+  }
+}
+
 template <int ROBOT, int NL>
 DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
                         const DevObsF* __restrict__ obsf, const double pos[3], const double Rw[9], const Smem& sm,
-                        bool live, bool& hit, unsigned& segmask) {
+                        const ScreenLds& L, bool live, bool& hit, unsigned& segmask) {
   using S = Shape<ROBOT, NL>;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = threadIdx.x & 63;
   const bool f32_safe = fmax(fabs(pos[0]), fmax(fabs(pos[1]), fabs(pos[2]))) + X->reach <= A.f32_range;
   double R[9], p[3];
 #pragma unroll
   for (int k = 0; k < 9; ++k) R[k] = Rw[k];
   p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
-  hit = false; segmask = 0u;
+  L.res[lane] = 0u;
+  unsigned head = 0, qn = 0;  // wave-uniform
 #pragma unroll 1
   for (int k = 0; k < S::kSeg; ++k) {
     if (k > 0) advance_frame(M, sm, tid, k, R, p);
     const int pb = X->seg_prim_begin[k], np = X->seg_prim_begin[k + 1] - pb;
     if (np == 0) continue;
-    PrimF32 Pf;
-    prims_f32<S::kGimbal>(A, M, X, pb, np, R, p, f32_safe, Pf);
+    float c[3 * kSegPrimMax];
+#pragma unroll
+    for (int j = 0; j < kSegPrimMax; ++j) {
+      c[3 * j] = c[3 * j + 1] = c[3 * j + 2] = 0.0f;
+      if (j < np) {
+        double pc[3];
+        prim_pose<S::kGimbal, false>(M, X->prim_order[pb + j], R, p, pc, nullptr);
+        c[3 * j] = static_cast<float>(pc[0]); c[3 * j + 1] = static_cast<float>(pc[1]); c[3 * j + 2] = static_cast<float>(pc[2]);
+      }
+    }
     double sc[3];
     xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
     unsigned gb, ge;
-    grid_cell(A.grid, sc, live && !hit, gb, ge);
-    bool maybe = false;
-#pragma unroll 1
-    for (unsigned g = gb; __any(g < ge); ++g) {
-      PROF_WAVE(5);
-      PROF_LANES(6, g < ge);
-      if (g < ge) {
-        const uint2 w = *reinterpret_cast<const uint2*>(A.grid.items + static_cast<size_t>(g) * kGridGroup);
-        const unsigned ids[kGridGroup] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
-        DevObsF F[kGridGroup];
+    grid_cell(A.grid, sc, live, gb, ge);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const bool push = gb < ge && !(__hip_atomic_load(L.res + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) & kResHit);
+    const unsigned long long bal = __ballot(push);
+    if (bal) {
+      const unsigned to = (head + qn + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)))) & (kRing - 1);
+      if (push) {
 #pragma unroll
-        for (int c = 0; c < kGridGroup; ++c) F[c] = obsf[ids[c] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[c]];
-#pragma unroll
-        for (int c = 0; c < kGridGroup; ++c) {
-          const bool real = ids[c] != kGridNone;
-          if (c > 0 && !__any(real)) break;  // lists are padded at the end only
-#pragma unroll
-          for (int j = 0; j < kSegPrimMax; ++j) {
-            if (j < np) {
-              const float l2 = point_box_dist2_f32(F[c], Pf.x[j], Pf.y[j], Pf.z[j]);
-              hit = hit || (real && l2 <= Pf.hit2[j]);
-              maybe = maybe || (real && l2 <= Pf.may2[j]);
-            }
-          }
-        }
-        if (hit) ge = gb;  // decided: stop fetching
+        for (int e = 0; e < 3 * kSegPrimMax; ++e) L.ring[e * kRing + to] = __float_as_uint(c[e]);
+        L.ring[(3 * kSegPrimMax) * kRing + to] = gb;
+        L.ring[(3 * kSegPrimMax + 1) * kRing + to] = ge;
+        L.ring[(3 * kSegPrimMax + 2) * kRing + to] = static_cast<unsigned>(lane) | (static_cast<unsigned>(k) << 6) |
+                                                     (f32_safe ? 1u << 10 : 0u) | (static_cast<unsigned>(np) << 11);
       }
+      qn += static_cast<unsigned>(__popcll(bal));
     }
-    segmask |= (maybe ? 1u : 0u) << k;
-    if (!__any(live && !hit)) break;
+#pragma unroll 1
+    while (qn >= 64u) screen_pop(A, obsf, L, head, qn);
   }
-  hit = hit && live;
-  segmask = live ? segmask : 0u;
+#pragma unroll 1
+  while (qn > 0u) screen_pop(A, obsf, L, head, qn);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const unsigned r = __hip_atomic_load(L.res + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  hit = live && (r & kResHit);
+  segmask = live ? (r & ~kResHit) : 0u;
 }
 
 // ------------------------------------------------------------------------
@@ -1212,7 +1310,18 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
   using S = Shape<ROBOT, NL>;
   constexpr int NJ = S::kJoint;
   __shared__ double sm_cs[2 * NJ * kBlock];
+  __shared__ unsigned sm_ring[(kBlock / 64) * kRingWords * kRing];
+  __shared__ unsigned sm_res[kBlock];
+  __shared__ float sm_thr[S::kSeg * kSegPrimMax * 2];
   Smem sm{(lds_double*)sm_cs, nullptr};
+  const ScreenLds L{(lds_uint*)sm_ring + (threadIdx.x >> 6) * (kRingWords * kRing), (lds_uint*)sm_res + (threadIdx.x & ~63), (lds_float*)sm_thr};
+  if (threadIdx.x < S::kSeg * kSegPrimMax) {
+    float h2, m2;
+    screen_thresholds(A, X, threadIdx.x / kSegPrimMax, threadIdx.x % kSegPrimMax, h2, m2);
+    L.thr[2 * threadIdx.x] = h2;
+    L.thr[2 * threadIdx.x + 1] = m2;
+  }
+  __syncthreads();
 
   const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool in_range = gi < A.n;
@@ -1224,12 +1333,6 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
   uint64_t edge;
   int step;
   fetch_state<NJ, EDGE, true>(A, li, st, edge, step);
-  // the root pose stays in LDS for the records of the undecided states (its registers are
-  // long dead by then; the joints' cos/sin are in sm.cs already)
-  __shared__ double sm_pose_[7 * kBlock];
-  lds_double* sm_pose = (lds_double*)sm_pose_;
-#pragma unroll
-  for (int r = 0; r < 7; ++r) sm_pose[r * kBlock + threadIdx.x] = st[r];
 
   StateOut o;
   double Rw[9];
@@ -1240,7 +1343,7 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
   const bool live = finite && A.do_coll && A.n_obs > 0 && (!A.do_stab || o.stable);
   bool hit = false;
   unsigned segmask = 0u;
-  if (__any(live)) collide_screen<ROBOT, NL>(A, M, X, obsf, st, Rw, sm, live, hit, segmask);
+  if (__any(live)) collide_screen<ROBOT, NL>(A, M, X, obsf, st, Rw, sm, L, live, hit, segmask);
   const bool undecided = in_range && live && !hit && segmask != 0u;
   PROF_LANES(0, true); PROF_LANES(1, live); PROF_LANES(2, hit); PROF_LANES(3, undecided); PROF_LANES(4, live && !hit && segmask == 0u);
 
@@ -1273,6 +1376,11 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
       // of one sparse sequence per (wave, segment).
       __shared__ unsigned sm_ent_slot[kBlock / 64][64];
       __shared__ unsigned short sm_ent_src[kBlock / 64][64];
+      // the root poses of this wave's lanes, [7][64], in the wave's (now idle) ring
+      static_assert(sizeof(unsigned) * kRingWords * kRing >= sizeof(double) * 7 * 64, "ring too small for the pose rows");
+      lds_double* sm_pose = (lds_double*)L.ring;
+#pragma unroll
+      for (int r = 0; r < 7; ++r) sm_pose[r * 64 + lane] = st[r];
       unsigned pos[S::kSeg];
       unsigned n_ent = 0;
 #pragma unroll
@@ -1309,7 +1417,7 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
           if (slot < A.queue_rec_cap) {
             double* __restrict__ dst = A.queue_rec + static_cast<uint64_t>(k) * kRec * A.queue_rec_cap + slot;
 #pragma unroll
-            for (int r = 0; r < 7; ++r) dst[static_cast<uint64_t>(r) * A.queue_rec_cap] = sm_pose[r * kBlock + src];
+            for (int r = 0; r < 7; ++r) dst[static_cast<uint64_t>(r) * A.queue_rec_cap] = sm_pose[r * 64 + (src & 63u)];
 #pragma unroll
             for (int r = 0; r < 2 * NJ; ++r)  // the frame of segment k turns on joints 0 .. k-1 only
               if (r < 2 * static_cast<int>(k)) dst[static_cast<uint64_t>(7 + r) * A.queue_rec_cap] = sm.cs[r * kBlock + src];
