@@ -32,9 +32,6 @@ namespace {
 // scalar helpers
 // ------------------------------------------------------------------------
 #define DEV __device__ __forceinline__
-#ifndef MVK_RSQ_MASK
-#define MVK_RSQ_MASK 7
-#endif
 
 // Diagnostic builds only (profiles/diag.py, -DMVK_PROF): event counters, one atomic per wave.
 #if defined(MVK_PROF) || defined(MVK_PROFT)
@@ -114,6 +111,12 @@ DEV double rsqrt_nr(double x) {
   y = fma(y, fma(-hx * y, y, 0.5), y);
   y = fma(y, fma(-hx * y, y, 0.5), y);
   return y;
+}
+
+// one Newton step: relative error ~1e-14, for scale factors of distances compared at 1e-5 / 1e-6
+DEV double rsqrt_nr1(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  return fma(y, fma(-0.5 * x * y, y, 0.5), y);
 }
 
 DEV double excess(double x, double h) {  // signed overshoot outside [-h, h]
@@ -531,13 +534,8 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
       for (int k = 0; k < c; ++k) s = fma(-Lm[r][k], Lm[c][k], s);
       if (r == c) {
         singular = singular || !(s > 1e-14 * trace);
-#if MVK_RSQ_MASK & 1
         Linv[r] = rsqrt_nr(s);
         Lm[r][r] = s * Linv[r];
-#else
-        Lm[r][r] = sqrt(s);
-        Linv[r] = 1.0 / Lm[r][r];
-#endif
       } else {
         Lm[r][c] = s * Linv[c];
       }
@@ -570,62 +568,52 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
   }
   if (singular) { lam_min = NAN; lam_max = NAN; }
 
-  // feasible-control torque distances: unordered pairs, both orientations at once
+  // feasible-control torque distances.  For the pair (i, j) with n = V_i x V_j the two one-sided
+  // sums over the other rotors are  dp = sum max(t_k, 0), dm = sum max(-t_k, 0), t_k = n . V_k, so
+  //   min(dp, dm) = (sum |t_k| - |sum t_k|) / 2   and   sum t_k = n . sum_k V_k
+  // (n is orthogonal to V_i and V_j): one dot product and one |.|-accumulate per rotor, and the
+  // scale fmax / |n| applied once.  The flag path skips the whole block when the test is off.
+  double Vs[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { Vs[0] += V[i][0]; Vs[1] += V[i][1]; Vs[2] += V[i][2]; }
   double fc_t = INFINITY;
+  // (not for the gimbal models: the branch costs their flag kernel more in spills than the block costs)
+  if (FULL || S::kGimbal || M->fc_t_min_thre > 0.0) {
 #pragma unroll
-  for (int i = 0; i < NL; ++i)
+    for (int i = 0; i < NL; ++i)
 #pragma unroll
-    for (int j = i + 1; j < NL; ++j) {
-      const double nx = fma(V[i][1], V[j][2], -V[i][2] * V[j][1]);
-      const double ny = fma(V[i][2], V[j][0], -V[i][0] * V[j][2]);
-      const double nz = fma(V[i][0], V[j][1], -V[i][1] * V[j][0]);
-      const double n2 = fma(nx, nx, fma(ny, ny, nz * nz));
-#if MVK_RSQ_MASK & 2
-      const double rn = rsqrt_nr(n2);
-      const double sc = !(n2 * rn >= 1e-5) ? 0.0 : fmaxT * rn;  // |n| < 1e-5 (n2 = 0 gives NaN): distance 0
-#else
-      const double nn = sqrt(n2);
-      const double sc = (nn < 1e-5) ? 0.0 : fmaxT / nn;
-#endif
-      double dp = 0.0, dm = 0.0;
+      for (int j = i + 1; j < NL; ++j) {
+        const double nx = fma(V[i][1], V[j][2], -V[i][2] * V[j][1]);
+        const double ny = fma(V[i][2], V[j][0], -V[i][0] * V[j][2]);
+        const double nz = fma(V[i][0], V[j][1], -V[i][1] * V[j][0]);
+        const double n2 = fma(nx, nx, fma(ny, ny, nz * nz));
+        const double rn = rsqrt_nr1(n2);
+        const double sc = !(n2 * rn >= 1e-5) ? 0.0 : (0.5 * fmaxT) * rn;  // |n| < 1e-5 (n2 = 0 gives NaN): distance 0
+        double sabs = 0.0;
 #pragma unroll
-      for (int k = 0; k < NL; ++k) {
-        if (k == i || k == j) continue;
-        const double tp = fma(nx, V[k][0], fma(ny, V[k][1], nz * V[k][2])) * sc;
-        dp += fmax(tp, 0.0);
-        dm += fmax(-tp, 0.0);
+        for (int k = 0; k < NL; ++k) {
+          if (k == i || k == j) continue;
+          sabs += fabs(fma(nx, V[k][0], fma(ny, V[k][1], nz * V[k][2])));
+        }
+        const double ssum = fma(nx, Vs[0], fma(ny, Vs[1], nz * Vs[2]));
+        fc_t = fmin(fc_t, fmax(sabs - fabs(ssum), 0.0) * sc);
       }
-      fc_t = fmin(fc_t, fmin(dp, dm));
-      // the pairs are independent: without a fence the scheduler interleaves all of them and
-      // the live ranges cost a wave of occupancy
-#ifdef MVK_SCHED_FENCE
-  #ifdef MVK_SCHED_FENCE
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#endif
-    }
-  // roll/pitch version
+  }
+  // roll/pitch version: d_i = sum_j max(c_ij, 0) = (sum c_ij + sum |c_ij|) / 2, c_ij = (V_i x V_j)_z, c_ii = 0
   double fc_rp = INFINITY;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const double na2 = fma(V[i][0], V[i][0], V[i][1] * V[i][1]);
-#if MVK_RSQ_MASK & 4
-    const double ra = rsqrt_nr(na2);
-    const double sc = !(na2 * ra >= 1e-5) ? 0.0 : fmaxT * ra;
-#else
-    const double na = sqrt(na2);
-    const double sc = (na < 1e-5) ? 0.0 : fmaxT / na;
-#endif
-    double d = 0.0;
+    const double ra = rsqrt_nr1(na2);
+    const double sc = !(na2 * ra >= 1e-5) ? 0.0 : (0.5 * fmaxT) * ra;
+    double sabs = 0.0;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       if (j == i) continue;
-      d += fmax(fma(V[i][1], V[j][0], -V[i][0] * V[j][1]) * sc, 0.0);
+      sabs += fabs(fma(V[i][1], V[j][0], -V[i][0] * V[j][1]));
     }
-    fc_rp = fmin(fc_rp, d);
-#ifdef MVK_SCHED_FENCE
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    const double ssum = fma(V[i][1], Vs[0], -V[i][0] * Vs[1]);
+    fc_rp = fmin(fc_rp, fmax(sabs + ssum, 0.0) * sc);
   }
   out.fc_t_min = fc_t;
   out.fc_rp_min = fc_rp;
