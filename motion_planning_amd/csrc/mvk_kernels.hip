@@ -368,7 +368,7 @@ struct Shape {
   static constexpr int rotor_seg(int i) { return kGimbal ? 2 * i : i; }
   // waves per SIMD the screen kernel is compiled for (caps its VGPRs at 512 / waves): the walk-1
   // arithmetic offers the scheduler more independent chains than pay off in registers
-  static constexpr int kScreenWaves = (!kGimbal && NL <= 4) ? 4 : 3;
+  static constexpr int kScreenWaves = (!kGimbal && NL <= 4) ? 4 : 3;  // (NL = 8: see the LDS budget in screen_kernel)
 };
 
 constexpr int kListCap = 32;     // full path: per-lane narrowphase candidates per primitive
@@ -829,7 +829,7 @@ DEV void prims_f32(const EvalArgs& A, const mvk_model* __restrict__ M, const Dev
 // lane's segment, ORs the verdict into that lane's result word and pushes the rest of the list
 // back.  Items of a state already known to collide are dropped.
 constexpr int kRing = 128;       // items per wave: < 64 waiting + at most 64 pushed by one segment
-constexpr int kRingWords = 3 * kSegPrimMax + 3;  // primitive centres, first group, end group, tag
+constexpr int kRingWords = 3 * kSegPrimMax + 2;  // primitive centres; first group + tag; end group + primitive count
 constexpr unsigned kResHit = 0x80000000u;
 
 struct ScreenLds {
@@ -861,18 +861,19 @@ DEV void screen_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const S
   PROF_WAVE(5);
   const bool active = static_cast<unsigned>(lane) < m;
   const unsigned at = (head + lane) & (kRing - 1);
-  unsigned g = 0, gend = 0, tag = 0;
+  unsigned wa = 0, wb = 0;
   float c[3 * kSegPrimMax];
   if (active) {
-    g = L.ring[(3 * kSegPrimMax) * kRing + at];
-    gend = L.ring[(3 * kSegPrimMax + 1) * kRing + at];
-    tag = L.ring[(3 * kSegPrimMax + 2) * kRing + at];
+    wa = L.ring[(3 * kSegPrimMax) * kRing + at];
+    wb = L.ring[(3 * kSegPrimMax + 1) * kRing + at];
 #pragma unroll
     for (int e = 0; e < 3 * kSegPrimMax; ++e) c[e] = __uint_as_float(L.ring[e * kRing + at]);
   }
-  const unsigned src = tag & 63u, k = (tag >> 6) & 15u;
-  const bool safe = (tag >> 10) & 1u;
-  const unsigned np = tag >> 11;
+  // word a: first group (21 bits: kGridMaxItems / kGridGroup), source lane (6), segment (4), fp32-safe (1)
+  // word b: end group (22 bits: it may equal the group count), primitives on the segment (2)
+  const unsigned g = wa & 0x1FFFFFu, src = (wa >> 21) & 63u, k = (wa >> 27) & 15u;
+  const bool safe = wa >> 31;
+  const unsigned gend = wb & 0x3FFFFFu, np = wb >> 22;
   bool work = active && !(__hip_atomic_load(L.res + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) & kResHit);
   PROF_LANES(6, work);
   bool more = false;
@@ -908,9 +909,8 @@ DEV void screen_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const S
     if (more) {
 #pragma unroll
       for (int e = 0; e < 3 * kSegPrimMax; ++e) L.ring[e * kRing + to] = __float_as_uint(c[e]);
-      L.ring[(3 * kSegPrimMax) * kRing + to] = g + 1;
-      L.ring[(3 * kSegPrimMax + 1) * kRing + to] = gend;
-      L.ring[(3 * kSegPrimMax + 2) * kRing + to] = tag;
+      L.ring[(3 * kSegPrimMax) * kRing + to] = wa + 1u;  // next group, same tag (g + 1 < gend: no carry into the tag)
+      L.ring[(3 * kSegPrimMax + 1) * kRing + to] = wb;
     }
     qn += static_cast<unsigned>(__popcll(bal));
   }
@@ -956,10 +956,9 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       if (push) {
 #pragma unroll
         for (int e = 0; e < 3 * kSegPrimMax; ++e) L.ring[e * kRing + to] = __float_as_uint(c[e]);
-        L.ring[(3 * kSegPrimMax) * kRing + to] = gb;
-        L.ring[(3 * kSegPrimMax + 1) * kRing + to] = ge;
-        L.ring[(3 * kSegPrimMax + 2) * kRing + to] = static_cast<unsigned>(lane) | (static_cast<unsigned>(k) << 6) |
-                                                     (f32_safe ? 1u << 10 : 0u) | (static_cast<unsigned>(np) << 11);
+        L.ring[(3 * kSegPrimMax) * kRing + to] = gb | (static_cast<unsigned>(lane) << 21) | (static_cast<unsigned>(k) << 27) |
+                                                 (f32_safe ? 1u << 31 : 0u);
+        L.ring[(3 * kSegPrimMax + 1) * kRing + to] = ge | (static_cast<unsigned>(np) << 22);
       }
       qn += static_cast<unsigned>(__popcll(bal));
     }
@@ -1362,11 +1361,13 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
       // consecutive slots), then lane e writes entry e: its index and its record, row by row, from
       // the pose / cos-sin rows of the source lane.  One coalesced store sequence per wave instead
       // of one sparse sequence per (wave, segment).
-      __shared__ unsigned sm_ent_slot[kBlock / 64][64];
-      __shared__ unsigned short sm_ent_src[kBlock / 64][64];
+
       // the root poses of this wave's lanes, [7][64], in the wave's (now idle) ring
-      static_assert(sizeof(unsigned) * kRingWords * kRing >= sizeof(double) * 7 * 64, "ring too small for the pose rows");
+      static_assert(sizeof(unsigned) * kRingWords * kRing >= sizeof(double) * 7 * 64 + 6 * 64, "ring too small for the pose rows and the entry list");
+      static_assert(kGridMaxItems / kGridGroup <= (1u << 21) && MVK_MAX_SEG <= 16 && kSegPrimMax <= 3, "ring item packing");
       lds_double* sm_pose = (lds_double*)L.ring;
+      lds_uint* ent_slot = L.ring + 7 * 64 * 2;                  // [64] after the pose rows
+      lds_ushort* ent_src = (lds_ushort*)(L.ring + 7 * 64 * 2 + 64);  // [64]
 #pragma unroll
       for (int r = 0; r < 7; ++r) sm_pose[r * 64 + lane] = st[r];
       unsigned pos[S::kSeg];
@@ -1392,15 +1393,15 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
             unsigned earlier = 0;
 #pragma unroll
             for (int k2 = 0; k2 < S::kSeg; ++k2) earlier += (k2 < k) ? sm_cnt[wv][k2] : 0u;
-            sm_ent_slot[wv][pos[k] - chunk] = sm_base[k] + before + (pos[k] - earlier);
-            sm_ent_src[wv][pos[k] - chunk] = static_cast<unsigned short>((k << 8) | threadIdx.x);
+            ent_slot[pos[k] - chunk] = sm_base[k] + before + (pos[k] - earlier);
+            ent_src[pos[k] - chunk] = static_cast<unsigned short>((k << 8) | threadIdx.x);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (chunk + lane < n_ent) {
-          const unsigned slot = sm_ent_slot[wv][lane];
-          const unsigned src = sm_ent_src[wv][lane] & 0xFFu, k = sm_ent_src[wv][lane] >> 8;
+          const unsigned slot = ent_slot[lane];
+          const unsigned src = ent_src[lane] & 0xFFu, k = ent_src[lane] >> 8;
           A.queue[static_cast<uint64_t>(k) * A.queue_stride + slot] = static_cast<uint32_t>(block_first + src);
           if (slot < A.queue_rec_cap) {
             double* __restrict__ dst = A.queue_rec + static_cast<uint64_t>(k) * kRec * A.queue_rec_cap + slot;
