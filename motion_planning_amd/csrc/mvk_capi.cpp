@@ -99,15 +99,13 @@ struct mvk_ctx {
   mvk_model* d_model = nullptr;
   DevExtras* d_extras = nullptr;
   Buf obs, obsf, grid_start, grid_items;
-  static constexpr size_t kQueueCounterBytes = 2 * static_cast<size_t>(MVK_MAX_SEG) * kQueueCounterPitch * sizeof(uint32_t);
-  // flag path work queues (per chain segment: the states the screen stage left undecided there) and
-  // their two alternating sets of counters: call k appends to set k%2 and zeroes set (k+1)%2, so no
-  // memset sits between launches.
-  // Calls on one ctx must therefore be ordered with respect to each other (one stream at a time).
+  // flag path hand-off between the screen and the exact stage (see EvalArgs).  Two alternating sets
+  // of queue counters: call k appends to set k%2 and zeroes set (k+1)%2, so no memset sits between
+  // launches.  Calls on one ctx must therefore be ordered with respect to each other (one stream at a time).
+  static constexpr size_t kQueueCounterSet = static_cast<size_t>(MVK_MAX_SEG) * kQueueShards * kQueueCounterPitch;  // words
   Buf queue, queue_rec, queue_counts;
   uint64_t call_index = 0;
   int n_cu = 256;
-  uint64_t rec_cap_override = 0;  // MVK_QUEUE_REC_CAP at creation (tests: exercise the entries without a record)
   // optional kernel timing (mvk_set_profiling): events around the kernels of the last call
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool profiling = false, timed = false;
@@ -324,31 +322,25 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
   a.nd_uniform = 1;
 }
 
-// flag path: size the per-segment work queues for n lanes and hand this call its set of counters
+// flag path: size the hand-off buffers between the screen stage and the exact stage for n lanes and
+// hand this call its set of counters
 int prepare_queue(mvk_ctx* c, EvalArgs& a, uint64_t n) {
   if (n > 0xffffffffULL) return fail(MVK_ERR_CAPACITY, "at most 2^32-1 states (or edge steps) per call");
   const uint64_t n_seg = static_cast<uint64_t>(c->model.n_seg);
-  if (int rc = c->queue.reserve(n_seg * n * sizeof(uint32_t))) return rc;
+  const uint64_t waves = (n + kBlock - 1) / kBlock * (kBlock / 64);
+  const uint64_t stride = (waves + kQueueShards - 1) / kQueueShards * 64;
+  const uint64_t rec_doubles = 8 + 2 * static_cast<uint64_t>(c->model.n_joint);
+  if (int rc = c->queue.reserve(n_seg * kQueueShards * stride * sizeof(uint32_t))) return rc;
+  if (int rc = c->queue_rec.reserve(waves * 64 * rec_doubles * sizeof(double))) return rc;
   uint32_t* counts = static_cast<uint32_t*>(c->queue_counts.p);
-  const size_t set = static_cast<size_t>(MVK_MAX_SEG) * kQueueCounterPitch;
-  // records for an eighth of the lanes per segment (typical scenes leave a few per cent undecided);
-  // the entries beyond go the slower way through the state rows
-  const uint64_t n_up = (n + kBlock - 1) / kBlock * kBlock;
-  uint64_t cap = ((n / 8) + kBlock - 1) / kBlock * kBlock;
-  if (cap < 4096) cap = 4096;
-  if (c->rec_cap_override > 0) cap = (c->rec_cap_override + kBlock - 1) / kBlock * kBlock;
-  if (cap > n_up) cap = n_up;
-  const uint64_t rec_doubles = 7 + 2 * static_cast<uint64_t>(c->model.n_joint);
-  if (int rc = c->queue_rec.reserve(n_seg * cap * rec_doubles * sizeof(double))) return rc;
+  a.queue = static_cast<uint32_t*>(c->queue.p);
+  a.queue_stride = stride;
+  a.queue_count = counts + (c->call_index & 1) * mvk_ctx::kQueueCounterSet;
+  a.queue_count_next = counts + ((c->call_index + 1) & 1) * mvk_ctx::kQueueCounterSet;
+  ++c->call_index;
   a.queue_rec = static_cast<double*>(c->queue_rec.p);
-  a.queue_rec_cap = cap;
   // the exact stage runs as many blocks as the chip holds at once (about three per CU)
   a.exact_blocks = static_cast<uint32_t>(3 * c->n_cu);
-  a.queue = static_cast<uint32_t*>(c->queue.p);
-  a.queue_stride = n;
-  a.queue_count = counts + (c->call_index & 1) * set;
-  a.queue_count_next = counts + ((c->call_index + 1) & 1) * set;
-  ++c->call_index;
   return MVK_OK;
 }
 
@@ -493,12 +485,11 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
     mvk_destroy(c);
     return nullptr;
   }
-  if (const char* e_cap = std::getenv("MVK_QUEUE_REC_CAP")) c->rec_cap_override = std::strtoull(e_cap, nullptr, 10);
-  if (c->queue_counts.reserve(mvk_ctx::kQueueCounterBytes) != MVK_OK) {
+  if (c->queue_counts.reserve(2 * mvk_ctx::kQueueCounterSet * sizeof(uint32_t)) != MVK_OK) {
     mvk_destroy(c);
     return nullptr;
   }
-  if ((e = hipMemset(c->queue_counts.p, 0, mvk_ctx::kQueueCounterBytes)) != hipSuccess) return bail("hipMemset(queue counters)", e);
+  if ((e = hipMemset(c->queue_counts.p, 0, 2 * mvk_ctx::kQueueCounterSet * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(queue counters)", e);
   return c;
 }
 

@@ -107,16 +107,14 @@ struct EvalArgs {
   double* gimbal;
   int32_t* first_invalid;  // edge mode: atomicMin target
   // flag path: states the fp32 screen leaves undecided, for the exact stage (ctx-owned)
-  // flag path work queues: one per chain segment, queue k = states with an undecided pair on segment k
-  uint32_t* queue;             // [n_seg][queue_stride] state indices
-  uint64_t queue_stride;       // capacity of each segment's queue (= n)
-  uint32_t* queue_count;       // [n_seg] counters kQueueCounterPitch words apart, appended to by this call (zero on entry)
+  // flag path hand-off from the screen stage to the exact stage: queues of state indices, one per
+  // (chain segment, shard); a screen wave appends to shard (wave index % kQueueShards) of a segment
+  uint32_t* queue;             // [n_seg * kQueueShards][queue_stride]
+  uint64_t queue_stride;       // capacity of one queue: every lane of every kQueueShards-th wave
+  uint32_t* queue_count;       // [n_seg * kQueueShards] counters kQueueCounterPitch words apart, appended to by this call (zero on entry)
   uint32_t* queue_count_next;  // same shape, zeroed by this call for the next one
-  // state records of the first queue_rec_cap entries of every segment's queue (root pose + joint
-  // cos/sin, kernels' record layout): the exact stage reads them instead of gathering the state rows
-  double* queue_rec;           // [n_seg][7 + 2 * n_joint][queue_rec_cap]
+  double* queue_rec;           // [lanes launched][8 + 2 * n_joint] per state: root pose, pad, (cos, sin) of every joint
   uint32_t exact_blocks;       // grid of the exact stage
-  uint64_t queue_rec_cap;      // multiple of kBlock; entries beyond it are re-fetched through queue[]
   // per-block partial statistics (full mode) or nullptr
   void* stats_partial;
   // C-space sweep (mvk_sweep_mask_dev): states are generated from the sample index, nothing is read
@@ -146,8 +144,10 @@ struct StatsPartial {
 };
 
 constexpr int kBlock = 256;
-constexpr int kSegPrimMax = 3;
-constexpr int kQueueCounterPitch = 64;  // uint32 words between two segment counters: one 256-byte line each  // collision primitives riding on one segment (checked by mvk_create)
+constexpr int kSegPrimMax = 3;           // collision primitives riding on one segment (checked by mvk_create)
+constexpr int kQueueShards = 8;         // queues per segment (MVK_MAX_SEG * kQueueShards counters per set)
+constexpr int kQueueCounterPitch = 64;  // uint32 words between two counters: one 256-byte line each
+
 
 // launchers implemented in mvk_kernels.hip; return hipError_t as int
 // events: nullptr, or hipEvent_t[3] recorded before / between / after the kernels of the call

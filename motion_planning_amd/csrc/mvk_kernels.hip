@@ -34,6 +34,9 @@ namespace {
 #define DEV __device__ __forceinline__
 
 // Diagnostic builds only (profiles/diag.py, -DMVK_PROF): event counters, one atomic per wave.
+#ifdef MVK_PROFS  // stage clocks of the screen kernel instead of the exact kernel's: same records, same host side
+#define MVK_PROFT
+#endif
 #if defined(MVK_PROF) || defined(MVK_PROFT)
 __device__ unsigned long long g_prof[48];
 #endif
@@ -360,8 +363,8 @@ struct Shape {
   static constexpr int kSeg = kGimbal ? 2 * NL - 1 : NL;
   static constexpr int kJoint = kGimbal ? 2 * (NL - 1) : NL - 1;
   static constexpr int kDof = kGimbal ? 3 : 4;
-  // rows of a queue record: root position and quaternion, cos/sin of every joint
-  static constexpr int kRec = 7 + 2 * kJoint;
+  // doubles of a state record of the flag path: root position and quaternion, a pad, (cos, sin) of every joint
+  static constexpr int kRecPad = 8 + 2 * kJoint;
   // joint axis of segment k (compile time): HYDRUS yaw chain; DRAGON pitch (odd) / yaw (even)
   static constexpr int axis(int k) { return kGimbal ? ((k & 1) ? 1 : 2) : 2; }
   static constexpr int joint(int k) { return k - 1; }
@@ -919,7 +922,7 @@ DEV void screen_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const S
 template <int ROBOT, int NL>
 DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
                         const DevObsF* __restrict__ obsf, const double pos[3], const double Rw[9], const Smem& sm,
-                        const ScreenLds& L, bool live, bool& hit, unsigned& segmask) {
+                        const ScreenLds& L, bool live, bool& hit, unsigned& segmask, unsigned long long* prof_pop) {
   using S = Shape<ROBOT, NL>;
   const int tid = threadIdx.x, lane = threadIdx.x & 63;
   const bool f32_safe = fmax(fabs(pos[0]), fmax(fabs(pos[1]), fabs(pos[2]))) + X->reach <= A.f32_range;
@@ -962,11 +965,23 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       }
       qn += static_cast<unsigned>(__popcll(bal));
     }
+#ifdef MVK_PROFS
+    const unsigned long long tp0 = wall_clock64();
+#endif
 #pragma unroll 1
     while (qn >= 64u) screen_pop(A, obsf, L, head, qn);
+#ifdef MVK_PROFS
+    *prof_pop += wall_clock64() - tp0;
+#endif
   }
+#ifdef MVK_PROFS
+  const unsigned long long tp1 = wall_clock64();
+#endif
 #pragma unroll 1
   while (qn > 0u) screen_pop(A, obsf, L, head, qn);
+#ifdef MVK_PROFS
+  *prof_pop += wall_clock64() - tp1;
+#endif
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const unsigned r = __hip_atomic_load(L.res + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1301,6 +1316,9 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
   __shared__ unsigned sm_res[kBlock];
   __shared__ float sm_thr[S::kSeg * kSegPrimMax * 2];
   Smem sm{(lds_double*)sm_cs, nullptr};
+#ifdef MVK_PROFS
+  const unsigned long long t_entry = wall_clock64();
+#endif
   const ScreenLds L{(lds_uint*)sm_ring + (threadIdx.x >> 6) * (kRingWords * kRing), (lds_uint*)sm_res + (threadIdx.x & ~63), (lds_float*)sm_thr};
   if (threadIdx.x < S::kSeg * kSegPrimMax) {
     float h2, m2;
@@ -1314,7 +1332,7 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
   const bool in_range = gi < A.n;
   const uint64_t li = in_range ? gi : (A.n - 1);  // clamp: out-of-range lanes redo the last state
   // the counters the NEXT call on this ctx appends to
-  if (gi < static_cast<uint64_t>(S::kSeg)) A.queue_count_next[gi * kQueueCounterPitch] = 0u;
+  if (gi < static_cast<uint64_t>(S::kSeg * kQueueShards)) A.queue_count_next[gi * kQueueCounterPitch] = 0u;
 
   double st[7 + NJ];
   uint64_t edge;
@@ -1330,88 +1348,55 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
   const bool live = finite && A.do_coll && A.n_obs > 0 && (!A.do_stab || o.stable);
   bool hit = false;
   unsigned segmask = 0u;
-  if (__any(live)) collide_screen<ROBOT, NL>(A, M, X, obsf, st, Rw, sm, L, live, hit, segmask);
+#ifdef MVK_PROFS
+  PROF_STAGE_DECL;
+  const unsigned long long t_w1 = wall_clock64();
+  PROF_STAGE(0, t_entry, t_w1);
+  unsigned long long prof_pop = 0;
+  if (__any(live)) collide_screen<ROBOT, NL>(A, M, X, obsf, st, Rw, sm, L, live, hit, segmask, &prof_pop);
+  const unsigned long long t_w2 = wall_clock64();
+  prof_d[1] += t_w2 - t_w1 - prof_pop;
+  prof_d[2] += prof_pop;
+#else
+  if (__any(live)) collide_screen<ROBOT, NL>(A, M, X, obsf, st, Rw, sm, L, live, hit, segmask, nullptr);
+#endif
   const bool undecided = in_range && live && !hit && segmask != 0u;
   PROF_LANES(0, true); PROF_LANES(1, live); PROF_LANES(2, hit); PROF_LANES(3, undecided); PROF_LANES(4, live && !hit && segmask == 0u);
 
-  // append this block's undecided (state, segment) pairs to the segments' queues: one atomic per
-  // segment and block, issued by S::kSeg lanes at once
+  // Hand the undecided (state, segment) pairs to the exact stage, wave by wave and without a block
+  // barrier: lane k of the wave reserves the wave's share of segment k's queue with one atomic (the
+  // queues are split kQueueShards ways by wave index, so that no counter sees more than a few
+  // thousand atomics per launch), the lanes write their state index behind it, and an undecided
+  // lane leaves its record (root pose, joint cos/sin) in the slot of its state.
   {
-    constexpr int kRec = S::kRec;
-    __shared__ unsigned sm_cnt[kBlock / 64][S::kSeg];
-    __shared__ unsigned sm_base[S::kSeg];
     const unsigned todo = undecided ? segmask : 0u;
-    if (__syncthreads_or(todo != 0u)) {
-      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (__any(todo != 0u)) {
+      const int lane = threadIdx.x & 63;
+      const unsigned shard = static_cast<unsigned>(gi >> 6) & (kQueueShards - 1);
+      unsigned long long bal[S::kSeg];
+      unsigned my_cnt = 0;
 #pragma unroll
       for (int k = 0; k < S::kSeg; ++k) {
-        const unsigned long long bal = __ballot((todo >> k) & 1u);
-        if (lane == 0) sm_cnt[wv][k] = static_cast<unsigned>(__popcll(bal));
+        bal[k] = __ballot((todo >> k) & 1u);
+        my_cnt = (lane == k) ? static_cast<unsigned>(__popcll(bal[k])) : my_cnt;
       }
-      __syncthreads();
-      if (threadIdx.x < S::kSeg) {
-        unsigned total = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) total += sm_cnt[w][threadIdx.x];
-        sm_base[threadIdx.x] = total ? atomicAdd(A.queue_count + threadIdx.x * kQueueCounterPitch, total) : 0u;
-      }
-      __syncthreads();
-      // Entry-major write-out: a wave holds a handful of entries spread over its lanes and the
-      // segments.  They are listed in LDS (segment-major, so neighbours share a queue and sit in
-      // consecutive slots), then lane e writes entry e: its index and its record, row by row, from
-      // the pose / cos-sin rows of the source lane.  One coalesced store sequence per wave instead
-      // of one sparse sequence per (wave, segment).
-
-      // the root poses of this wave's lanes, [7][64], in the wave's (now idle) ring
-      static_assert(sizeof(unsigned) * kRingWords * kRing >= sizeof(double) * 7 * 64 + 6 * 64, "ring too small for the pose rows and the entry list");
-      static_assert(kGridMaxItems / kGridGroup <= (1u << 21) && MVK_MAX_SEG <= 16 && kSegPrimMax <= 3, "ring item packing");
-      lds_double* sm_pose = (lds_double*)L.ring;
-      lds_uint* ent_slot = L.ring + 7 * 64 * 2;                  // [64] after the pose rows
-      lds_ushort* ent_src = (lds_ushort*)(L.ring + 7 * 64 * 2 + 64);  // [64]
-#pragma unroll
-      for (int r = 0; r < 7; ++r) sm_pose[r * 64 + lane] = st[r];
-      unsigned pos[S::kSeg];
-      unsigned n_ent = 0;
+      unsigned my_base = 0;
+      if (lane < S::kSeg && my_cnt) my_base = atomicAdd(A.queue_count + (lane * kQueueShards + shard) * kQueueCounterPitch, my_cnt);
 #pragma unroll
       for (int k = 0; k < S::kSeg; ++k) {
-        const unsigned long long bal = __ballot((todo >> k) & 1u);
-        pos[k] = n_ent + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)));
-        n_ent += static_cast<unsigned>(__popcll(bal));
+        const unsigned base_k = __builtin_amdgcn_readlane(my_base, k);
+        if ((todo >> k) & 1u)
+          A.queue[static_cast<uint64_t>(k * kQueueShards + shard) * A.queue_stride + base_k + __popcll(bal[k] & ((1ull << lane) - 1ull))] =
+              static_cast<uint32_t>(gi);
       }
-      const uint64_t block_first = static_cast<uint64_t>(blockIdx.x) * kBlock;
-#pragma unroll 1
-      for (unsigned chunk = 0; chunk < n_ent; chunk += 64) {  // wave-uniform; one pass unless most lanes are undecided
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+      if (todo != 0u) {
+        double2* __restrict__ dst = reinterpret_cast<double2*>(A.queue_rec + gi * S::kRecPad);
+        dst[0] = make_double2(st[0], st[1]);
+        dst[1] = make_double2(st[2], st[3]);
+        dst[2] = make_double2(st[4], st[5]);
+        dst[3] = make_double2(st[6], 0.0);
 #pragma unroll
-        for (int k = 0; k < S::kSeg; ++k) {
-          if (((todo >> k) & 1u) && pos[k] - chunk < 64u) {
-            unsigned before = 0;
-#pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) before += (w < wv) ? sm_cnt[w][k] : 0u;
-            // rank within the segment's share of this wave = pos[k] - (entries of earlier segments)
-            unsigned earlier = 0;
-#pragma unroll
-            for (int k2 = 0; k2 < S::kSeg; ++k2) earlier += (k2 < k) ? sm_cnt[wv][k2] : 0u;
-            ent_slot[pos[k] - chunk] = sm_base[k] + before + (pos[k] - earlier);
-            ent_src[pos[k] - chunk] = static_cast<unsigned short>((k << 8) | threadIdx.x);
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (chunk + lane < n_ent) {
-          const unsigned slot = ent_slot[lane];
-          const unsigned src = ent_src[lane] & 0xFFu, k = ent_src[lane] >> 8;
-          A.queue[static_cast<uint64_t>(k) * A.queue_stride + slot] = static_cast<uint32_t>(block_first + src);
-          if (slot < A.queue_rec_cap) {
-            double* __restrict__ dst = A.queue_rec + static_cast<uint64_t>(k) * kRec * A.queue_rec_cap + slot;
-#pragma unroll
-            for (int r = 0; r < 7; ++r) dst[static_cast<uint64_t>(r) * A.queue_rec_cap] = sm_pose[r * 64 + (src & 63u)];
-#pragma unroll
-            for (int r = 0; r < 2 * NJ; ++r)  // the frame of segment k turns on joints 0 .. k-1 only
-              if (r < 2 * static_cast<int>(k)) dst[static_cast<uint64_t>(7 + r) * A.queue_rec_cap] = sm.cs[r * kBlock + src];
-          }
-        }
+        for (int j = 0; j < NJ; ++j) dst[4 + j] = make_double2(sm.cs[(2 * j) * kBlock + threadIdx.x], sm.cs[(2 * j + 1) * kBlock + threadIdx.x]);
       }
     }
   }
@@ -1431,6 +1416,10 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
     if (in_range && !valid) atomicMin(&A.first_invalid[edge], step);
     if (A.band && in_range && band) A.band[edge] = 1;
   }
+#ifdef MVK_PROFS
+  { const unsigned long long t_end = wall_clock64(); prof_d[3] += t_end - t_w2; }
+  PROF_STAGE_FLUSH;
+#endif
 }
 
 template <int ROBOT, int NL, bool EDGE>
@@ -1451,49 +1440,62 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   lds_double* frames = (lds_double*)sm_frame_;
   const int tid = threadIdx.x, lane = threadIdx.x & 63;
 
+#ifndef MVK_PROFS
   PROF_T(t_entry);
   PROF_STAGE_DECL;
-  // the segments' queues laid end to end in chunks of one block; the grid strides over the chunks
-  unsigned first[S::kSeg + 1];  // written by screen_kernel, the launch before on this stream
-  first[0] = 0;
+#endif
+  // The queues (segment-major, kQueueShards per segment) laid end to end in chunks of one block;
+  // the grid strides over the chunks.  sm_first[q] = first chunk of queue q.
+  constexpr int kQueues = S::kSeg * kQueueShards;
+  static_assert(kQueues <= 64, "one wave scans the queue lengths");
+  __shared__ unsigned sm_first[kQueues + 1];
+  if (tid < 64) {  // counters written by screen_kernel, the launch before on this stream
+    const unsigned mine_chunks = tid < kQueues ? (A.queue_count[tid * kQueueCounterPitch] + kBlock - 1) / kBlock : 0u;
+    unsigned incl = mine_chunks;
 #pragma unroll
-  for (int k = 0; k < S::kSeg; ++k) first[k + 1] = first[k] + (A.queue_count[k * kQueueCounterPitch] + kBlock - 1) / kBlock;
-  for (unsigned chunk = blockIdx.x; chunk < first[S::kSeg]; chunk += gridDim.x) {
-    int ks = 0;  // the chain segment this chunk belongs to (block-uniform)
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off);
+      if (tid >= off) incl += o;
+    }
+    if (tid == 0) sm_first[0] = 0u;
+    if (tid < kQueues) sm_first[tid + 1] = incl;
+  }
+  __syncthreads();
+  const unsigned n_chunks = sm_first[kQueues];
+  for (unsigned chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    unsigned lo = 0, hi = kQueues;  // the queue holding this chunk: the last q with first[q] <= chunk (block-uniform)
 #pragma unroll
-    for (int k = 1; k < S::kSeg; ++k) ks = (chunk >= first[k]) ? k : ks;
-    const unsigned count = A.queue_count[ks * kQueueCounterPitch];
-    const uint32_t* __restrict__ queue = A.queue + static_cast<uint64_t>(ks) * A.queue_stride;
+    for (int it = 0; it < 6; ++it) {
+      const unsigned mid = (lo + hi) >> 1;
+      if (hi - lo > 1) { if (sm_first[mid] <= chunk) lo = mid; else hi = mid; }
+    }
+    const int ks = static_cast<int>(lo / kQueueShards);  // the chain segment
+    const unsigned count = A.queue_count[lo * kQueueCounterPitch];
+    const uint32_t* __restrict__ queue = A.queue + static_cast<uint64_t>(lo) * A.queue_stride;
     const int pb = X->seg_prim_begin[ks], np = X->seg_prim_begin[ks + 1] - pb;
-    unsigned chunk_first = 0;
-#pragma unroll
-    for (int k = 1; k < S::kSeg; ++k) chunk_first = (ks == k) ? first[k] : chunk_first;
-    const uint64_t base = static_cast<uint64_t>(chunk - chunk_first) * kBlock;
-    const uint64_t qi = base + tid;
+    const unsigned base = (chunk - sm_first[lo]) * kBlock;
+  {
+    const unsigned qi = base + tid;
     const bool mine = qi < count;
     const uint64_t gi = queue[mine ? qi : (count - 1)];
+#ifndef MVK_PROFS
     PROF_T(t_q);
     PROF_STAGE(0, t_entry, t_q);
-    double st[7 + NJ], R[9], p[3];
+#endif
+    double st[7], R[9], p[3];
     if (tid < kSegPrimMax) sm_nitems[tid] = 0u;
     sm_hit[tid] = 0;
-    if (base < A.queue_rec_cap) {  // block-uniform: the screen stage left a record
-      const double* __restrict__ rec = A.queue_rec + static_cast<uint64_t>(ks) * S::kRec * A.queue_rec_cap + (mine ? qi : (count - 1));
-#pragma unroll
-      for (int r = 0; r < 7; ++r) st[r] = rec[static_cast<uint64_t>(r) * A.queue_rec_cap];
-#pragma unroll
-      for (int r = 0; r < 2 * NJ; ++r)
-        if (r < 2 * ks) sm.cs[r * kBlock + tid] = rec[static_cast<uint64_t>(7 + r) * A.queue_rec_cap];
-    } else {
-      uint64_t edge;
-      int step;
-      fetch_state<NJ, EDGE, true>(A, gi, st, edge, step);
+    {
+      const double2* __restrict__ rec = reinterpret_cast<const double2*>(A.queue_rec + gi * S::kRecPad);
+      const double2 v0 = rec[0], v1 = rec[1], v2 = rec[2], v3 = rec[3];
+      st[0] = v0.x; st[1] = v0.y; st[2] = v1.x; st[3] = v1.y; st[4] = v2.x; st[5] = v2.y; st[6] = v3.x;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        double sj, cj;
-        sincos_cw(st[7 + j], sj, cj);
-        sm.cs[(2 * j) * kBlock + tid] = cj;
-        sm.cs[(2 * j + 1) * kBlock + tid] = sj;
+        if (j < ks) {  // the frame of segment ks turns on joints 0 .. ks-1 only
+          const double2 v = rec[4 + j];
+          sm.cs[(2 * j) * kBlock + tid] = v.x;
+          sm.cs[(2 * j + 1) * kBlock + tid] = v.y;
+        }
       }
     }
     quat_to_mat(st[3], st[4], st[5], st[6], R);
@@ -1507,8 +1509,10 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 #pragma unroll
     for (int e = 0; e < 3; ++e) frames[(9 + e) * kBlock + tid] = p[e];
     __syncthreads();  // the cos/sin region is dead from here on: it becomes the pair list
+#ifndef MVK_PROFS
     PROF_T(t_fk);
     PROF_STAGE(1, t_q, t_fk);
+#endif
 
     // ---- level 1: the fp32 screen again; the pairs it cannot clear go to the BLOCK's list --------
     // (a lane's serial work would be its own longest list; shared out, it is the block's mean)
@@ -1553,8 +1557,10 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       }
     }
     __syncthreads();
+#ifndef MVK_PROFS
     PROF_T(t_l1);
     PROF_STAGE(2, t_fk, t_l1);
+#endif
 
     // ---- level 2: exact tests, one pair per lane, primitive kind wave-uniform ---------------------
 #pragma unroll
@@ -1593,8 +1599,10 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       }
     }
     __syncthreads();
+#ifndef MVK_PROFS
     PROF_T(t_l2);
     PROF_STAGE(3, t_l1, t_l2);
+#endif
     const bool hit = mine && sm_hit[tid] != 0;
     PROF_LANES(13, hit);
     if (hit) {  // the screen wrote this state as valid-so-far
@@ -1609,7 +1617,10 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       }
     }
   }
-  if (blockIdx.x < first[S::kSeg]) PROF_STAGE_FLUSH;
+  }
+#ifndef MVK_PROFS
+  if (blockIdx.x < n_chunks) PROF_STAGE_FLUSH;
+#endif
 }
 
 template <int ROBOT, int NL>

@@ -52,6 +52,8 @@ def prof_counters(w, d, mask):
     print("   counters: " + ", ".join(f"{PROF_NAMES[k]}={buf[k]}" for k in sorted(PROF_NAMES)), flush=True)
     waves = max(int(buf[15]), 1)
     stages = ["entry->queue", "fetch+frame", "level 1", "level 2"]
+    if os.environ.get("MVK_DIAG_SCREEN"):   # library built with -DMVK_PROFS: the same slots hold the screen kernel's stages
+        stages = ["fetch+walk 1", "walk 2 per-segment part", "walk 2 pops", "tail"]
     print("   exact_kernel stage clocks (us, mean over waves / max): " +
           ", ".join(f"{nm} {buf[16 + 2 * i] / waves / 100:.2f}/{buf[17 + 2 * i] / 100:.2f}" for i, nm in enumerate(stages)) +
           f"; first entry -> last exit {(buf[41] - buf[40]) / 100:.2f}, waves {waves}", flush=True)

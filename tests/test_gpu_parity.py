@@ -264,31 +264,24 @@ def test_candidate_list_overflow_falls_back_to_full_sweep():
     assert 0 < ref["flags"].sum() < n   # the case is not degenerate
 
 
-def test_queue_entries_without_a_record_take_the_state_rows(monkeypatch):
-    """The screen stage leaves a compact record (pose + joint cos/sin) for the first entries of every
-    segment's queue only; the entries beyond are re-fetched from the state rows.  With the record
-    capacity forced down to one block both ways must give the same bits, for states and for edges."""
-    n = 40000
-    w = common.config2(n=n)
-    ref = O.flags_only(w.model, w.boxes, w.params, w.soa, w.layout, threads=8)
+def test_exact_stage_groups_and_ragged_tail():
+    """The exact stage compacts the undecided lanes of 128 screen waves at a time: batches that end inside a wave,
+    inside a block and inside a group of waves, and more than one group, against the oracle (states and edges)."""
+    w = common.config2(n=3 * 8192 + 777)
     full = O.eval_batch(w.model, w.boxes, w.params, w.soa, w.layout, threads=8)
-    model, params, boxes, s1, s2, nd = common.config4(n_edges=3000)
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    for n in (1, 63, 65, 257, 8191, 8193, 3 * 8192 + 777):
+        got = eng.is_valid_batch(w.soa[:, :n], w.layout)["flags"]
+        band = full["band"][:n].astype(bool)
+        assert not np.any((got != full["flags"][:n]) & ~band), n
+    eng.close()
+    model, params, boxes, s1, s2, nd = common.config4(n_edges=700)
     ok_ref, first_ref, band_ref = O.check_motion_batch(model, boxes, params, s1, s2, nd)
-    for cap in (None, "256"):
-        if cap is None:
-            monkeypatch.delenv("MVK_QUEUE_REC_CAP", raising=False)
-        else:
-            monkeypatch.setenv("MVK_QUEUE_REC_CAP", cap)
-        eng = mp.Engine(w.model, w.boxes, w.params)
-        got = eng.is_valid_batch(w.soa, w.layout)["flags"]
-        eng.close()
-        band = full["band"].astype(bool)
-        assert not np.any((got != ref) & ~band), cap
-        eng = mp.Engine(model, boxes, params)
-        ok, first = eng.check_motion_batch(s1, s2, nd)[:2]
-        eng.close()
-        sure = ~band_ref.astype(bool)
-        assert np.array_equal(ok[sure], ok_ref[sure]) and np.array_equal(first[sure], first_ref[sure]), cap
+    eng = mp.Engine(model, boxes, params)
+    ok, first = eng.check_motion_batch(s1, s2, nd)[:2]
+    eng.close()
+    sure = ~band_ref.astype(bool)
+    assert np.array_equal(ok[sure], ok_ref[sure]) and np.array_equal(first[sure], first_ref[sure])
 
 
 # ---------------------------------------------------------------------------
