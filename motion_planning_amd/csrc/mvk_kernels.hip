@@ -932,11 +932,37 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
   p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
   L.res[lane] = 0u;
   unsigned head = 0, qn = 0;  // wave-uniform
+  // push the item of one segment (centres c, list [gb, ge), tag bits) unless the list is empty or
+  // the state is already known to collide
+  auto push_item = [&](const float* c, unsigned gb, unsigned ge, unsigned tag_a, unsigned tag_b) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const bool push = gb < ge && !(__hip_atomic_load(L.res + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) & kResHit);
+    const unsigned long long bal = __ballot(push);
+    if (bal) {
+      const unsigned to = (head + qn + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)))) & (kRing - 1);
+      if (push) {
+#pragma unroll
+        for (int e = 0; e < 3 * kSegPrimMax; ++e) L.ring[e * kRing + to] = __float_as_uint(c[e]);
+        L.ring[(3 * kSegPrimMax) * kRing + to] = gb | tag_a;
+        L.ring[(3 * kSegPrimMax + 1) * kRing + to] = ge | tag_b;
+      }
+      qn += static_cast<unsigned>(__popcll(bal));
+    }
+  };
+  // The lookup of a segment's grid cell is a dependent global load; its result is consumed one
+  // segment later (software pipeline of depth one), behind the next segment's frame arithmetic.
+  float pc_[3 * kSegPrimMax];
+  unsigned p_gb = 0, p_ge = 0, p_ta = 0, p_tb = 0;
+  bool pending = false;  // wave-uniform
 #pragma unroll 1
   for (int k = 0; k < S::kSeg; ++k) {
     if (k > 0) advance_frame(M, sm, tid, k, R, p);
     const int pb = X->seg_prim_begin[k], np = X->seg_prim_begin[k + 1] - pb;
     if (np == 0) continue;
+    double sc[3];
+    xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
+    unsigned gb, ge;
+    grid_cell(A.grid, sc, live, gb, ge);
     float c[3 * kSegPrimMax];
 #pragma unroll
     for (int j = 0; j < kSegPrimMax; ++j) {
@@ -947,24 +973,13 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
         c[3 * j] = static_cast<float>(pc[0]); c[3 * j + 1] = static_cast<float>(pc[1]); c[3 * j + 2] = static_cast<float>(pc[2]);
       }
     }
-    double sc[3];
-    xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
-    unsigned gb, ge;
-    grid_cell(A.grid, sc, live, gb, ge);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const bool push = gb < ge && !(__hip_atomic_load(L.res + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) & kResHit);
-    const unsigned long long bal = __ballot(push);
-    if (bal) {
-      const unsigned to = (head + qn + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)))) & (kRing - 1);
-      if (push) {
+    if (pending) push_item(pc_, p_gb, p_ge, p_ta, p_tb);
 #pragma unroll
-        for (int e = 0; e < 3 * kSegPrimMax; ++e) L.ring[e * kRing + to] = __float_as_uint(c[e]);
-        L.ring[(3 * kSegPrimMax) * kRing + to] = gb | (static_cast<unsigned>(lane) << 21) | (static_cast<unsigned>(k) << 27) |
-                                                 (f32_safe ? 1u << 31 : 0u);
-        L.ring[(3 * kSegPrimMax + 1) * kRing + to] = ge | (static_cast<unsigned>(np) << 22);
-      }
-      qn += static_cast<unsigned>(__popcll(bal));
-    }
+    for (int e = 0; e < 3 * kSegPrimMax; ++e) pc_[e] = c[e];
+    p_gb = gb; p_ge = ge;
+    p_ta = (static_cast<unsigned>(lane) << 21) | (static_cast<unsigned>(k) << 27) | (f32_safe ? 1u << 31 : 0u);
+    p_tb = static_cast<unsigned>(np) << 22;
+    pending = true;
 #ifdef MVK_PROFS
     const unsigned long long tp0 = wall_clock64();
 #endif
@@ -974,6 +989,7 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
     *prof_pop += wall_clock64() - tp0;
 #endif
   }
+  if (pending) push_item(pc_, p_gb, p_ge, p_ta, p_tb);
 #ifdef MVK_PROFS
   const unsigned long long tp1 = wall_clock64();
 #endif
