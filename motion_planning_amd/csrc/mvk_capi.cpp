@@ -205,6 +205,20 @@ void derive_extras(const mvk_model* m, DevExtras* x) {
         }
       x->reach = std::fmax(x->reach, chain + norm3(c) + r);
     }
+    SegTab& T = x->seg_tab[k];
+    for (int a = 0; a < 3; ++a) { T.t[a] = m->seg_t[k][a]; T.sph[a] = c[a]; }
+    T.axis = m->seg_axis[k];
+    T.joint = m->seg_joint[k];
+    T.np = 0;
+    for (int q = 0; q < m->n_prim; ++q)
+      if (m->prim_seg[q] == k && T.np < kSegPrimMax) {
+        for (int a = 0; a < 3; ++a) {
+          T.prim_pos[T.np][a] = m->prim_pos[q][a];
+          T.gimbal_pos[T.np][a] = m->prim_frame[q] == MVK_FRAME_SEG ? 0.0 : m->rotor_pos[m->prim_rotor[q]][a];
+        }
+        T.prim_frame[T.np] = m->prim_frame[q];
+        ++T.np;
+      }
     x->seg_sph[k][0] = c[0]; x->seg_sph[k][1] = c[1]; x->seg_sph[k][2] = c[2];
     x->seg_sph[k][3] = r * (1.0 + 1e-12) + 1e-12;
   }

@@ -33,6 +33,19 @@ struct alignas(64) DevObsF {
 };
 
 // Model constants derived once on the host.
+constexpr int kSegPrimMax = 3;           // collision primitives riding on one segment (checked by mvk_create)
+
+// Everything walk 2 of the screen stage reads for one chain segment, in one place: one batch of
+// independent scalar loads per segment instead of chains through prim_order[] and prim_rotor[].
+struct SegTab {
+  double t[3];                          // origin in the parent segment frame (mvk_model::seg_t)
+  double sph[3];                        // centre of the segment's bounding sphere
+  double prim_pos[kSegPrimMax][3];      // collision origins, in their frame
+  double gimbal_pos[kSegPrimMax][3];    // gimbal centre carrying the primitive (frame != SEG)
+  int32_t axis, joint, np, pad;
+  int32_t prim_frame[kSegPrimMax + 1];  // MVK_FRAME_*
+};
+
 struct DevExtras {
   double tan_edf_max_tilt;
   double prim_bound[MVK_MAX_PRIM];  // radius about the primitive origin containing it
@@ -41,6 +54,7 @@ struct DevExtras {
   int32_t prim_order[MVK_MAX_PRIM];
   double seg_sph[MVK_MAX_SEG][4];  // per segment: sphere (centre in the segment frame, radius) holding its primitives
   double reach;                    // bound on the distance of any primitive point from the root origin
+  SegTab seg_tab[MVK_MAX_SEG];
 };
 
 // ---- broadphase grid (mvk_grid.cpp) ---------------------------------------
@@ -144,7 +158,6 @@ struct StatsPartial {
 };
 
 constexpr int kBlock = 256;
-constexpr int kSegPrimMax = 3;           // collision primitives riding on one segment (checked by mvk_create)
 constexpr int kQueueShards = 8;         // queues per segment (MVK_MAX_SEG * kQueueShards counters per set)
 constexpr int kQueueCounterPitch = 64;  // uint32 words between two counters: one 256-byte line each
 

@@ -956,20 +956,38 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
   bool pending = false;  // wave-uniform
 #pragma unroll 1
   for (int k = 0; k < S::kSeg; ++k) {
-    if (k > 0) advance_frame(M, sm, tid, k, R, p);
-    const int pb = X->seg_prim_begin[k], np = X->seg_prim_begin[k + 1] - pb;
+    const SegTab& T = X->seg_tab[k];
+    if (k > 0) {
+      double pn[3];
+      xform(R, p, T.t[0], T.t[1], T.t[2], pn);
+      p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+      rot_cols_dyn(R, T.axis, sm.cs[(2 * T.joint) * kBlock + tid], sm.cs[(2 * T.joint + 1) * kBlock + tid]);
+    }
+    const int np = T.np;
     if (np == 0) continue;
     double sc[3];
-    xform(R, p, X->seg_sph[k][0], X->seg_sph[k][1], X->seg_sph[k][2], sc);
+    xform(R, p, T.sph[0], T.sph[1], T.sph[2], sc);
     unsigned gb, ge;
     grid_cell(A.grid, sc, live, gb, ge);
+    double gcr = 1.0, gsr = 0.0, gcp = 1.0, gsp = 0.0;
+    if (S::kGimbal) gimbal_cs(R[6], R[7], R[8], gcr, gsr, gcp, gsp);
     float c[3 * kSegPrimMax];
 #pragma unroll
     for (int j = 0; j < kSegPrimMax; ++j) {
       c[3 * j] = c[3 * j + 1] = c[3 * j + 2] = 0.0f;
       if (j < np) {
         double pc[3];
-        prim_pose<S::kGimbal, false>(M, X->prim_order[pb + j], R, p, pc, nullptr);
+        if (S::kGimbal && T.prim_frame[j] != MVK_FRAME_SEG) {  // on the gimbal's roll (or roll + pitch) frame
+          double B[9], o[3];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) B[e] = R[e];
+          xform(R, p, T.gimbal_pos[j][0], T.gimbal_pos[j][1], T.gimbal_pos[j][2], o);
+          rot_cols<0>(B, gcr, gsr);
+          if (T.prim_frame[j] == MVK_FRAME_GIMBAL_PITCH) rot_cols<1>(B, gcp, gsp);
+          xform(B, o, T.prim_pos[j][0], T.prim_pos[j][1], T.prim_pos[j][2], pc);
+        } else {
+          xform(R, p, T.prim_pos[j][0], T.prim_pos[j][1], T.prim_pos[j][2], pc);
+        }
         c[3 * j] = static_cast<float>(pc[0]); c[3 * j + 1] = static_cast<float>(pc[1]); c[3 * j + 2] = static_cast<float>(pc[2]);
       }
     }
