@@ -21,6 +21,7 @@
 #include <mutex>
 #include <thread>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -174,8 +175,51 @@ void sample_uniform(const mvk_params& p, int J, Rng& rng, double* s) {
 
 // nearest tree node under the space's distance (mvk_space_distance), the tree read column-wise so
 // that the per-node arithmetic vectorises; `scratch` holds one distance per node
+// SE(2) base + J joints in one pass over the nodes: the whole compound distance per node, then the argmin
+template <int JT>
+inline __attribute__((always_inline)) int nearest_se2_fused(const mvk_params& p, const Tree& t, const double* s, double* __restrict__ acc) {
+  const int n = t.size();
+  const double* __restrict__ cx = t.col[0].data();
+  const double* __restrict__ cy = t.col[1].data();
+  const double* __restrict__ cw = t.col[2].data();
+  const double* __restrict__ cj[JT > 0 ? JT : 1];
+  double qj[JT > 0 ? JT : 1];
+  for (int j = 0; j < JT; ++j) { cj[j] = t.col[3 + j].data(); qj[j] = s[3 + j]; }
+  const double qx = s[0], qy = s[1], qw = s[2], w = p.joint_subspace_weight;
+#pragma clang loop vectorize(enable) interleave(enable)
+  for (int i = 0; i < n; ++i) {
+    double sj = 0.0;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) { const double d = cj[j][i] - qj[j]; sj += d * d; }
+    const double dx = cx[i] - qx, dy = cy[i] - qy;
+    double g = std::fabs(cw[i] - qw);
+    g = g > kPi ? 2.0 * kPi - g : g;
+    acc[i] = (std::sqrt(dx * dx + dy * dy) + 0.5 * g) + w * std::sqrt(sj);
+  }
+  double bd = INFINITY;  // the minimum (vectorises), then its first index
+  for (int i = 0; i < n; ++i) bd = acc[i] < bd ? acc[i] : bd;
+  int best = 0;
+  while (best < n - 1 && acc[best] != bd) ++best;
+  return best;
+}
+
+// the same loop compiled for AVX2 + FMA (picked at run time) and for the baseline ISA
+__attribute__((target("avx2,fma"))) int nearest_se2_avx2(const mvk_params& p, int J, const Tree& t, const double* s, double* acc) {
+  return J == 3 ? nearest_se2_fused<3>(p, t, s, acc) : J == 5 ? nearest_se2_fused<5>(p, t, s, acc) : nearest_se2_fused<7>(p, t, s, acc);
+}
+int nearest_se2_base(const mvk_params& p, int J, const Tree& t, const double* s, double* acc) {
+  return J == 3 ? nearest_se2_fused<3>(p, t, s, acc) : J == 5 ? nearest_se2_fused<5>(p, t, s, acc) : nearest_se2_fused<7>(p, t, s, acc);
+}
+
 int nearest(const mvk_params& p, int J, const Tree& t, const double* s, double* dist_out, std::vector<double>& scratch) {
   const int n = t.size();
+  if (p.planning_mode == MVK_MODE_JOINTS_AND_BASE && p.motion_type == MVK_SE2 && (J == 3 || J == 5 || J == 7)) {
+    static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    if (static_cast<int>(scratch.size()) < n) scratch.resize(static_cast<size_t>(n) + 256);
+    const int best = avx2 ? nearest_se2_avx2(p, J, t, s, scratch.data()) : nearest_se2_base(p, J, t, s, scratch.data());
+    *dist_out = mvk_space_distance(&p, J, t.at(best), s);
+    return best;
+  }
   scratch.assign(n, 0.0);
   double* acc = scratch.data();
   const bool has_base = p.planning_mode != MVK_MODE_ONLY_JOINTS, has_joints = p.planning_mode != MVK_MODE_ONLY_BASE;
@@ -228,7 +272,7 @@ struct EdgeBatch {  // SoA staging for one check_motions call
   std::vector<double> a, b;
   std::vector<int32_t> nd, first;
   std::vector<uint8_t> ok;
-  void pack(const std::vector<const double*>& from, const std::vector<std::vector<double>>& to, const mvk_params& p, int J) {
+  void pack(const std::vector<const double*>& from, const std::vector<const double*>& to, const mvk_params& p, int J) {
     const size_t n = from.size();
     a.assign(n * dim, 0.0);
     b.assign(n * dim, 0.0);
@@ -240,7 +284,7 @@ struct EdgeBatch {  // SoA staging for one check_motions call
         a[static_cast<size_t>(r) * n + e] = from[e][r];
         b[static_cast<size_t>(r) * n + e] = to[e][r];
       }
-      int c = mvk_space_valid_segment_count(&p, J, from[e], to[e].data());
+      int c = mvk_space_valid_segment_count(&p, J, from[e], to[e]);
       nd[e] = c < 1 ? 1 : c;
     }
   }
@@ -282,10 +326,18 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
   tree[1].add(req->goal, -1);
   EdgeBatch eb;
   eb.dim = dim;
+  // MVK_PLAN_TRACE=1: where the wall time of the search goes (stderr)
+  const bool trace = std::getenv("MVK_PLAN_TRACE") != nullptr;
+  double t_sample = 0, t_near = 0, t_pack = 0, t_check = 0, t_tree = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   int link[2] = {-1, -1};  // indices of the two nodes that meet (same state in both trees)
   bool solved = false;
   int cur = 0;
 
+  std::vector<const double*> from, to;
+  std::vector<int> from_idx, near_a, near_idx, fresh;
+  std::vector<double> samples, targets, dist_a;
   while (!solved) {
     if (req->max_iterations > 0 && out->iterations >= static_cast<uint64_t>(req->max_iterations)) break;
     if (req->time_limit_s > 0.0 && elapsed_ms() > req->time_limit_s * 1e3) break;
@@ -293,46 +345,53 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
     Tree& ta = tree[cur];
     Tree& tb = tree[1 - cur];
     // ---- EXTEND: `batch` independent samples, one launch -------------------
-    std::vector<const double*> from;
-    std::vector<std::vector<double>> to;
-    std::vector<int> from_idx;
-    std::vector<std::vector<double>> samples(batch, std::vector<double>(dim));
-    for (int k = 0; k < batch; ++k) sample_uniform(p, J, rng, samples[k].data());
-    std::vector<int> near_a(batch);
-    std::vector<double> dist_a(batch);
+    from.clear();
+    to.clear();
+    from_idx.clear();
+    auto tA = now();
+    samples.resize(static_cast<size_t>(batch) * dim);
+    targets.resize(static_cast<size_t>(batch) * dim);
+    for (int k = 0; k < batch; ++k) sample_uniform(p, J, rng, samples.data() + static_cast<size_t>(k) * dim);
+    t_sample += since(tA); tA = now();
+    near_a.resize(batch);
+    dist_a.resize(batch);
     {
       const bool wide = static_cast<int64_t>(batch) * ta.size() > 20000;
       auto job = [&](int k) {
         thread_local std::vector<double> scratch;
-        near_a[k] = nearest(p, J, ta, samples[k].data(), &dist_a[k], scratch);
+        near_a[k] = nearest(p, J, ta, samples.data() + static_cast<size_t>(k) * dim, &dist_a[k], scratch);
       };
       if (wide) Workers::get().parallel_for(batch, job);
       else for (int k = 0; k < batch; ++k) job(k);
     }
+    t_near += since(tA); tA = now();
     for (int k = 0; k < batch; ++k) {
       const double d = dist_a[k];
       const int ni = near_a[k];
-      std::vector<double> tgt(dim);
-      if (d > range) mvk_space_interpolate(&p, J, ta.at(ni), samples[k].data(), range / d, tgt.data());
-      else tgt = samples[k];
       if (!(d > 0.0)) continue;
+      const double* smp = samples.data() + static_cast<size_t>(k) * dim;
+      double* tgt = targets.data() + to.size() * dim;
+      if (d > range) mvk_space_interpolate(&p, J, ta.at(ni), smp, range / d, tgt);
+      else std::memcpy(tgt, smp, sizeof(double) * dim);
       from_idx.push_back(ni);
-      to.push_back(std::move(tgt));
+      to.push_back(tgt);
     }
     if (to.empty()) continue;
     for (int ni : from_idx) from.push_back(ta.at(ni));
     eb.pack(from, to, p, J);
+    t_pack += since(tA); tA = now();
     if (int rc = ck->check_motions(ck->user, eb.a.data(), eb.b.data(), to.size(), to.size(), eb.nd.data(), eb.ok.data(), eb.first.data())) return rc;
+    t_check += since(tA); tA = now();
     out->edge_checks += to.size();
     for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
-    std::vector<int> fresh;
+    fresh.clear();
     for (size_t e = 0; e < to.size(); ++e)
-      if (eb.ok[e]) fresh.push_back(ta.add(to[e].data(), from_idx[e]));
+      if (eb.ok[e]) fresh.push_back(ta.add(to[e], from_idx[e]));
+    t_tree += since(tA); tA = now();
     if (fresh.empty()) { cur = 1 - cur; continue; }
     // ---- CONNECT: straight shots from the other tree toward every fresh node ----
     from.clear();
-    std::vector<std::vector<double>> goal_states;
-    std::vector<int> near_idx;
+    to.clear();
     near_idx.resize(fresh.size());
     {
       const int nf = static_cast<int>(fresh.size());
@@ -345,10 +404,14 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
       if (wide) Workers::get().parallel_for(nf, job);
       else for (int e = 0; e < nf; ++e) job(e);
     }
-    for (int fi : fresh) goal_states.emplace_back(ta.at(fi), ta.at(fi) + dim);
+    t_near += since(tA); tA = now();
+    // (the trees only grow after the check below, so pointers into them stay valid while it runs)
+    for (int fi : fresh) to.push_back(ta.at(fi));
     for (int ni : near_idx) from.push_back(tb.at(ni));
-    eb.pack(from, goal_states, p, J);
+    eb.pack(from, to, p, J);
+    t_pack += since(tA); tA = now();
     if (int rc = ck->check_motions(ck->user, eb.a.data(), eb.b.data(), fresh.size(), fresh.size(), eb.nd.data(), eb.ok.data(), eb.first.data())) return rc;
+    t_check += since(tA); tA = now();
     out->edge_checks += fresh.size();
     for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
     for (size_t e = 0; e < fresh.size() && !solved; ++e) {
@@ -365,9 +428,13 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
         tb.add(adv.data(), near_idx[e]);
       }
     }
+    t_tree += since(tA);
     cur = 1 - cur;
   }
   out->solve_ms = elapsed_ms();
+  if (trace)
+    std::fprintf(stderr, "[mvk plan] %.2f ms, %llu iterations: sample %.2f, nearest %.2f, interpolate+pack %.2f, check_motions %.2f, tree %.2f\n",
+                 out->solve_ms, static_cast<unsigned long long>(out->iterations), t_sample, t_near, t_pack, t_check, t_tree);
   out->tree_sizes[0] = tree[0].size();
   out->tree_sizes[1] = tree[1].size();
   if (!solved) return fail(MVK_ERR_NO_SOLUTION, "No solution found");
