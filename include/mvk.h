@@ -329,6 +329,13 @@ int mvk_collision_avoidance_batch_dev(mvk_ctx* ctx, const double* d_soa, size_t 
 int mvk_check_motion_batch(mvk_ctx* ctx, const double* s1_soa, const double* s2_soa,
                            size_t n_edges, size_t ld, const int32_t* nd, int32_t nd_uniform,
                            uint8_t* ok, int32_t* first_invalid);
+/* The same call in two halves (no counterpart in the reference: OMPL's checkMotion blocks).
+ * begin copies the edges, enqueues the transfers and the kernels on the ctx's stream and returns;
+ * end waits for them and writes the verdicts.  Exactly one end per begin, no other call on the
+ * ctx in between.  mvk_check_motion_batch is begin followed by end. */
+int mvk_check_motion_batch_begin(mvk_ctx* ctx, const double* s1_soa, const double* s2_soa,
+                                 size_t n_edges, size_t ld, const int32_t* nd, int32_t nd_uniform);
+int mvk_check_motion_batch_end(mvk_ctx* ctx, uint8_t* ok, int32_t* first_invalid);
 int mvk_check_motion_batch_dev(mvk_ctx* ctx, const double* d_s1, const double* d_s2,
                                size_t n_edges, size_t ld, const int32_t* d_nd, int32_t nd_uniform,
                                uint8_t* d_ok, int32_t* d_first_invalid, void* stream);
@@ -362,6 +369,12 @@ typedef struct mvk_checker {
   int (*check_motions)(void* user, const double* s1, const double* s2, size_t n_edges, size_t ld,
                        const int32_t* nd, uint8_t* ok, int32_t* first_invalid);
   void* user;
+  /* optional (may be NULL, both or neither): the same edge check in two halves.  begin takes the
+   * edges and returns once the work is under way; end blocks and delivers the verdicts of the
+   * last begin.  With them the planner searches its trees while the GPU checks. */
+  int (*check_motions_begin)(void* user, const double* s1, const double* s2, size_t n_edges, size_t ld,
+                             const int32_t* nd);
+  int (*check_motions_end)(void* user, uint8_t* ok, int32_t* first_invalid);
 } mvk_checker;
 
 typedef struct mvk_plan_request {

@@ -86,7 +86,8 @@ CHECK_MOTIONS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POI
 
 
 class Checker(C.Structure):
-    _fields_ = [("check_states", CHECK_STATES_FN), ("check_motions", CHECK_MOTIONS_FN), ("user", C.c_void_p)]
+    _fields_ = [("check_states", CHECK_STATES_FN), ("check_motions", CHECK_MOTIONS_FN), ("user", C.c_void_p),
+                ("check_motions_begin", C.c_void_p), ("check_motions_end", C.c_void_p)]   # optional split interface (NULL here)
 
 
 class PlanRequest(C.Structure):
@@ -144,6 +145,8 @@ PROTOTYPES = {
     "mvk_collision_avoidance_batch": (ip, [vp, vp, sz, sz, ip, C.POINTER(AvoidParams), C.POINTER(AvoidOut)]),
     "mvk_collision_avoidance_batch_dev": (ip, [vp, vp, sz, sz, ip, C.POINTER(AvoidParams), C.POINTER(AvoidOut), vp]),
     "mvk_check_motion_batch": (ip, [vp, vp, vp, sz, sz, vp, i32, vp, vp]),
+    "mvk_check_motion_batch_begin": (ip, [vp, vp, vp, sz, sz, vp, i32]),
+    "mvk_check_motion_batch_end": (ip, [vp, vp, vp]),
     "mvk_check_motion_batch_dev": (ip, [vp, vp, vp, sz, sz, vp, i32, vp, vp, vp]),
     "mvk_space_dim": (ip, [PP, ip]),
     "mvk_space_distance": (d, [PP, ip, vp, vp]),

@@ -106,6 +106,9 @@ struct mvk_ctx {
   Buf queue, queue_rec, queue_counts;
   uint64_t call_index = 0;
   int n_cu = 256;
+  // mvk_check_motion_batch_begin / _end
+  bool edges_pending = false;
+  size_t edges_in_flight = 0, edges_nd_off = 0;
   // optional kernel timing (mvk_set_profiling): events around the kernels of the last call
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool profiling = false, timed = false;
@@ -885,12 +888,15 @@ extern "C" int mvk_check_motion_batch_dev(mvk_ctx* c, const double* d_s1, const 
   return run_edges_dev(c, d_s1, d_s2, n_edges, ld, d_nd, d_off, total, nd_uniform, d_ok, d_first, s);
 }
 
-extern "C" int mvk_check_motion_batch(mvk_ctx* c, const double* s1, const double* s2, size_t n_edges, size_t ld,
-                                      const int32_t* nd, int32_t nd_uniform, uint8_t* ok, int32_t* first_invalid) {
+extern "C" int mvk_check_motion_batch_begin(mvk_ctx* c, const double* s1, const double* s2, size_t n_edges, size_t ld,
+                                            const int32_t* nd, int32_t nd_uniform) {
   if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  if (c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "mvk_check_motion_batch_begin: the last begin has not been ended");
+  c->edges_in_flight = 0;
+  c->edges_pending = true;
   if (n_edges == 0) return MVK_OK;
+  c->edges_pending = false;
   if (!s1 || !s2 || ld < n_edges) return fail(MVK_ERR_INVALID_ARG, "bad edge arrays (null, or ld < n_edges)");
-  if (!ok && !first_invalid) return fail(MVK_ERR_INVALID_ARG, "no output requested");
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   // This is the planner's inner loop (hundreds of small calls per solve), so the call is shaped for
@@ -930,12 +936,36 @@ extern "C" int mvk_check_motion_batch(mvk_ctx* c, const double* s1, const double
                              nd ? reinterpret_cast<const int64_t*>(dev + off_off) : nullptr, total, nu, nullptr,
                              reinterpret_cast<int32_t*>(dev + off_first), s, /*first_is_initialised=*/true))
     return rc;
-  int32_t* down = static_cast<int32_t*>(c->pin_down.p);
-  HIP_TRY(hipMemcpyAsync(down, dev + off_first, n_edges * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipMemcpyAsync(c->pin_down.p, dev + off_first, n_edges * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  c->edges_in_flight = n_edges;
+  c->edges_nd_off = off_nd;
+  c->edges_pending = true;
+  return MVK_OK;
+}
+
+extern "C" int mvk_check_motion_batch_end(mvk_ctx* c, uint8_t* ok, int32_t* first_invalid) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  if (!c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "mvk_check_motion_batch_end without a begin");
+  c->edges_pending = false;
+  const size_t n_edges = c->edges_in_flight;
+  if (n_edges == 0) return MVK_OK;
+  if (!ok && !first_invalid) return fail(MVK_ERR_INVALID_ARG, "no output requested");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const int32_t* down = static_cast<const int32_t*>(c->pin_down.p);
+  const int32_t* hnd = reinterpret_cast<const int32_t*>(static_cast<const char*>(c->pin_up.p) + c->edges_nd_off);
   for (size_t e = 0; e < n_edges; ++e) {
     if (first_invalid) first_invalid[e] = down[e];
     if (ok) ok[e] = down[e] == hnd[e] + 1 ? 1 : 0;
   }
   return MVK_OK;
+}
+
+extern "C" int mvk_check_motion_batch(mvk_ctx* c, const double* s1, const double* s2, size_t n_edges, size_t ld,
+                                      const int32_t* nd, int32_t nd_uniform, uint8_t* ok, int32_t* first_invalid) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  if (n_edges == 0) return MVK_OK;
+  if (!ok && !first_invalid) return fail(MVK_ERR_INVALID_ARG, "no output requested");
+  if (int rc = mvk_check_motion_batch_begin(c, s1, s2, n_edges, ld, nd, nd_uniform)) return rc;
+  return mvk_check_motion_batch_end(c, ok, first_invalid);
 }

@@ -177,14 +177,14 @@ void sample_uniform(const mvk_params& p, int J, Rng& rng, double* s) {
 // that the per-node arithmetic vectorises; `scratch` holds one distance per node
 // SE(2) base + J joints in one pass over the nodes: the whole compound distance per node, then the argmin
 template <int JT>
-inline __attribute__((always_inline)) int nearest_se2_fused(const mvk_params& p, const Tree& t, const double* s, double* __restrict__ acc) {
-  const int n = t.size();
-  const double* __restrict__ cx = t.col[0].data();
-  const double* __restrict__ cy = t.col[1].data();
-  const double* __restrict__ cw = t.col[2].data();
+inline __attribute__((always_inline)) int nearest_se2_fused(const mvk_params& p, const Tree& t, int b0, const double* s, double* __restrict__ acc) {
+  const int n = t.size() - b0;  // nodes b0 .. size-1
+  const double* __restrict__ cx = t.col[0].data() + b0;
+  const double* __restrict__ cy = t.col[1].data() + b0;
+  const double* __restrict__ cw = t.col[2].data() + b0;
   const double* __restrict__ cj[JT > 0 ? JT : 1];
   double qj[JT > 0 ? JT : 1];
-  for (int j = 0; j < JT; ++j) { cj[j] = t.col[3 + j].data(); qj[j] = s[3 + j]; }
+  for (int j = 0; j < JT; ++j) { cj[j] = t.col[3 + j].data() + b0; qj[j] = s[3 + j]; }
   const double qx = s[0], qy = s[1], qw = s[2], w = p.joint_subspace_weight;
 #pragma clang loop vectorize(enable) interleave(enable)
   for (int i = 0; i < n; ++i) {
@@ -200,24 +200,34 @@ inline __attribute__((always_inline)) int nearest_se2_fused(const mvk_params& p,
   for (int i = 0; i < n; ++i) bd = acc[i] < bd ? acc[i] : bd;
   int best = 0;
   while (best < n - 1 && acc[best] != bd) ++best;
-  return best;
+  return b0 + best;
 }
 
 // the same loop compiled for AVX2 + FMA (picked at run time) and for the baseline ISA
-__attribute__((target("avx2,fma"))) int nearest_se2_avx2(const mvk_params& p, int J, const Tree& t, const double* s, double* acc) {
-  return J == 3 ? nearest_se2_fused<3>(p, t, s, acc) : J == 5 ? nearest_se2_fused<5>(p, t, s, acc) : nearest_se2_fused<7>(p, t, s, acc);
+__attribute__((target("avx2,fma"))) int nearest_se2_avx2(const mvk_params& p, int J, const Tree& t, int b0, const double* s, double* acc) {
+  return J == 3 ? nearest_se2_fused<3>(p, t, b0, s, acc) : J == 5 ? nearest_se2_fused<5>(p, t, b0, s, acc) : nearest_se2_fused<7>(p, t, b0, s, acc);
 }
-int nearest_se2_base(const mvk_params& p, int J, const Tree& t, const double* s, double* acc) {
-  return J == 3 ? nearest_se2_fused<3>(p, t, s, acc) : J == 5 ? nearest_se2_fused<5>(p, t, s, acc) : nearest_se2_fused<7>(p, t, s, acc);
+int nearest_se2_base(const mvk_params& p, int J, const Tree& t, int b0, const double* s, double* acc) {
+  return J == 3 ? nearest_se2_fused<3>(p, t, b0, s, acc) : J == 5 ? nearest_se2_fused<5>(p, t, b0, s, acc) : nearest_se2_fused<7>(p, t, b0, s, acc);
 }
 
-int nearest(const mvk_params& p, int J, const Tree& t, const double* s, double* dist_out, std::vector<double>& scratch) {
+int nearest(const mvk_params& p, int J, const Tree& t, const double* s, double* dist_out, std::vector<double>& scratch, int b0 = 0) {
   const int n = t.size();
   if (p.planning_mode == MVK_MODE_JOINTS_AND_BASE && p.motion_type == MVK_SE2 && (J == 3 || J == 5 || J == 7)) {
     static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
     if (static_cast<int>(scratch.size()) < n) scratch.resize(static_cast<size_t>(n) + 256);
-    const int best = avx2 ? nearest_se2_avx2(p, J, t, s, scratch.data()) : nearest_se2_base(p, J, t, s, scratch.data());
+    const int best = avx2 ? nearest_se2_avx2(p, J, t, b0, s, scratch.data()) : nearest_se2_base(p, J, t, b0, s, scratch.data());
     *dist_out = mvk_space_distance(&p, J, t.at(best), s);
+    return best;
+  }
+  if (b0 > 0) {  // general spaces: plain scan of the nodes from b0 on
+    int best = b0;
+    double bd = INFINITY;
+    for (int i = b0; i < n; ++i) {
+      const double d = mvk_space_distance(&p, J, t.at(i), s);
+      if (d < bd) { bd = d; best = i; }
+    }
+    *dist_out = bd;
     return best;
   }
   scratch.assign(n, 0.0);
@@ -336,8 +346,32 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
   int cur = 0;
 
   std::vector<const double*> from, to;
-  std::vector<int> from_idx, near_a, near_idx, fresh;
-  std::vector<double> samples, targets, dist_a;
+  std::vector<int> from_idx, near_a, near_idx, near_conn, fresh;
+  std::vector<double> samples, targets, dist_a, dist_conn;
+  bool have_next = false;  // samples / near_a / dist_a already hold the coming iteration's batch
+  // nearest node of `t` among nodes b0.. for each of n query states (row-major); `merge` keeps an
+  // earlier result when it is at least as close (ties go to the lower index, as one scan would)
+  auto search_all = [&](const Tree& t, int b0, const double* q, int n, std::vector<int>& idx, std::vector<double>& dst, bool merge) {
+    if (!merge) { idx.resize(n); dst.resize(n); }
+    const bool wide = static_cast<int64_t>(n) * (t.size() - b0) > 20000;
+    auto job = [&](int k) {
+      thread_local std::vector<double> scratch;
+      double d;
+      const int i = nearest(p, J, t, q + static_cast<size_t>(k) * dim, &d, scratch, b0);
+      if (!merge || d < dst[k]) { idx[k] = i; dst[k] = d; }
+    };
+    if (wide) Workers::get().parallel_for(n, job);
+    else for (int k = 0; k < n; ++k) job(k);
+  };
+  // the edge check in two halves, so that host work can run while the GPU checks (a checker
+  // without the split interface does all its work in the second half)
+  auto check_begin = [&](size_t n) -> int {
+    return ck->check_motions_begin ? ck->check_motions_begin(ck->user, eb.a.data(), eb.b.data(), n, n, eb.nd.data()) : 0;
+  };
+  auto check_end = [&](size_t n) -> int {
+    return ck->check_motions_begin ? ck->check_motions_end(ck->user, eb.ok.data(), eb.first.data())
+                                   : ck->check_motions(ck->user, eb.a.data(), eb.b.data(), n, n, eb.nd.data(), eb.ok.data(), eb.first.data());
+  };
   while (!solved) {
     if (req->max_iterations > 0 && out->iterations >= static_cast<uint64_t>(req->max_iterations)) break;
     if (req->time_limit_s > 0.0 && elapsed_ms() > req->time_limit_s * 1e3) break;
@@ -349,22 +383,15 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
     to.clear();
     from_idx.clear();
     auto tA = now();
-    samples.resize(static_cast<size_t>(batch) * dim);
     targets.resize(static_cast<size_t>(batch) * dim);
-    for (int k = 0; k < batch; ++k) sample_uniform(p, J, rng, samples.data() + static_cast<size_t>(k) * dim);
-    t_sample += since(tA); tA = now();
-    near_a.resize(batch);
-    dist_a.resize(batch);
-    {
-      const bool wide = static_cast<int64_t>(batch) * ta.size() > 20000;
-      auto job = [&](int k) {
-        thread_local std::vector<double> scratch;
-        near_a[k] = nearest(p, J, ta, samples.data() + static_cast<size_t>(k) * dim, &dist_a[k], scratch);
-      };
-      if (wide) Workers::get().parallel_for(batch, job);
-      else for (int k = 0; k < batch; ++k) job(k);
+    if (!have_next) {  // (otherwise drawn and searched while the last connect check was in flight)
+      samples.resize(static_cast<size_t>(batch) * dim);
+      for (int k = 0; k < batch; ++k) sample_uniform(p, J, rng, samples.data() + static_cast<size_t>(k) * dim);
+      t_sample += since(tA); tA = now();
+      search_all(ta, 0, samples.data(), batch, near_a, dist_a, false);
+      t_near += since(tA); tA = now();
     }
-    t_near += since(tA); tA = now();
+    have_next = false;
     for (int k = 0; k < batch; ++k) {
       const double d = dist_a[k];
       const int ni = near_a[k];
@@ -380,37 +407,42 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
     for (int ni : from_idx) from.push_back(ta.at(ni));
     eb.pack(from, to, p, J);
     t_pack += since(tA); tA = now();
-    if (int rc = ck->check_motions(ck->user, eb.a.data(), eb.b.data(), to.size(), to.size(), eb.nd.data(), eb.ok.data(), eb.first.data())) return rc;
+    if (int rc = check_begin(to.size())) return rc;
+    // while the check is in flight: where every proposed node would connect to in the other tree
+    const int n_prop = static_cast<int>(to.size());
+    search_all(tb, 0, targets.data(), n_prop, near_conn, dist_conn, false);
+    t_near += since(tA); tA = now();
+    if (int rc = check_end(to.size())) return rc;
     t_check += since(tA); tA = now();
     out->edge_checks += to.size();
     for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
     fresh.clear();
+    near_idx.clear();
     for (size_t e = 0; e < to.size(); ++e)
-      if (eb.ok[e]) fresh.push_back(ta.add(to[e], from_idx[e]));
+      if (eb.ok[e]) {
+        fresh.push_back(ta.add(to[e], from_idx[e]));
+        near_idx.push_back(near_conn[e]);
+      }
     t_tree += since(tA); tA = now();
     if (fresh.empty()) { cur = 1 - cur; continue; }
     // ---- CONNECT: straight shots from the other tree toward every fresh node ----
     from.clear();
     to.clear();
-    near_idx.resize(fresh.size());
-    {
-      const int nf = static_cast<int>(fresh.size());
-      const bool wide = static_cast<int64_t>(nf) * tb.size() > 20000;
-      auto job = [&](int e) {
-        thread_local std::vector<double> scratch;
-        double d;
-        near_idx[e] = nearest(p, J, tb, ta.at(fresh[e]), &d, scratch);
-      };
-      if (wide) Workers::get().parallel_for(nf, job);
-      else for (int e = 0; e < nf; ++e) job(e);
-    }
-    t_near += since(tA); tA = now();
     // (the trees only grow after the check below, so pointers into them stay valid while it runs)
     for (int fi : fresh) to.push_back(ta.at(fi));
     for (int ni : near_idx) from.push_back(tb.at(ni));
     eb.pack(from, to, p, J);
     t_pack += since(tA); tA = now();
-    if (int rc = ck->check_motions(ck->user, eb.a.data(), eb.b.data(), fresh.size(), fresh.size(), eb.nd.data(), eb.ok.data(), eb.first.data())) return rc;
+    if (int rc = check_begin(fresh.size())) return rc;
+    // while the check is in flight: the next iteration extends tb -- draw its samples and search
+    // tb as it stands; the nodes this connect adds are searched afterwards
+    const int tb_before = tb.size();
+    samples.resize(static_cast<size_t>(batch) * dim);
+    for (int k = 0; k < batch; ++k) sample_uniform(p, J, rng, samples.data() + static_cast<size_t>(k) * dim);
+    t_sample += since(tA); tA = now();
+    search_all(tb, 0, samples.data(), batch, near_a, dist_a, false);
+    t_near += since(tA); tA = now();
+    if (int rc = check_end(fresh.size())) return rc;
     t_check += since(tA); tA = now();
     out->edge_checks += fresh.size();
     for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
@@ -428,6 +460,10 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
         tb.add(adv.data(), near_idx[e]);
       }
     }
+    t_tree += since(tA); tA = now();
+    if (!solved && tb.size() > tb_before) search_all(tb, tb_before, samples.data(), batch, near_a, dist_a, true);
+    have_next = true;
+    t_near += since(tA); tA = now();
     t_tree += since(tA);
     cur = 1 - cur;
   }
@@ -460,6 +496,12 @@ int gpu_check_motions(void* user, const double* s1, const double* s2, size_t n, 
                       uint8_t* ok, int32_t* first) {
   return mvk_check_motion_batch(static_cast<mvk_ctx*>(user), s1, s2, n, ld, nd, 0, ok, first);
 }
+int gpu_check_motions_begin(void* user, const double* s1, const double* s2, size_t n, size_t ld, const int32_t* nd) {
+  return mvk_check_motion_batch_begin(static_cast<mvk_ctx*>(user), s1, s2, n, ld, nd, 0);
+}
+int gpu_check_motions_end(void* user, uint8_t* ok, int32_t* first) {
+  return mvk_check_motion_batch_end(static_cast<mvk_ctx*>(user), ok, first);
+}
 }  // namespace
 
 extern "C" int mvk_plan_rrt_connect(mvk_ctx* ctx, const mvk_plan_request* req, double* waypoints, int cap,
@@ -468,7 +510,7 @@ extern "C" int mvk_plan_rrt_connect(mvk_ctx* ctx, const mvk_plan_request* req, d
   mvk_params p;
   if (int rc = mvk_get_params(ctx, &p)) return rc;
   const int J = mvk_state_dim(ctx, MVK_LAYOUT_POSE7) - 7;
-  mvk_checker ck{gpu_check_states, gpu_check_motions, ctx};
+  mvk_checker ck{gpu_check_states, gpu_check_motions, ctx, gpu_check_motions_begin, gpu_check_motions_end};
   return mvk_plan_rrt_connect_cb(&p, J, &ck, req, waypoints, cap, out);
 }
 
