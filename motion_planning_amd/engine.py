@@ -255,6 +255,27 @@ class Engine:
                                                          _ptr(ok), _ptr(first)))
         return ok, first
 
+    def check_motion_batch_begin(self, s1, s2, nd):
+        """first half of check_motion_batch: returns once the transfers and kernels are enqueued"""
+        s1 = np.ascontiguousarray(s1, dtype=np.float64)
+        s2 = np.ascontiguousarray(s2, dtype=np.float64)
+        rows, E = s1.shape
+        assert s2.shape == s1.shape and rows == self.state_dim(A.LAYOUT_OMPL)
+        if np.isscalar(nd):
+            nd_arr, nd_u = None, int(nd)
+        else:
+            nd_arr, nd_u = np.ascontiguousarray(nd, dtype=np.int32), 0
+        self._pending_edges = E
+        _check(self.lib, self.lib.mvk_check_motion_batch_begin(self.ctx, _ptr(s1), _ptr(s2), E, E, _ptr(nd_arr), nd_u))
+
+    def check_motion_batch_end(self):
+        """second half: waits and returns (ok, first_invalid) of the last begin"""
+        E = getattr(self, "_pending_edges", 0)
+        ok = np.zeros(E, np.uint8)
+        first = np.zeros(E, np.int32)
+        _check(self.lib, self.lib.mvk_check_motion_batch_end(self.ctx, _ptr(ok), _ptr(first)))
+        return ok, first
+
     # ---- device-pointer entry points (torch tensors resident in HBM) ----------
     @staticmethod
     def _dp(t):

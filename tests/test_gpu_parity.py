@@ -284,6 +284,23 @@ def test_exact_stage_groups_and_ragged_tail():
     assert np.array_equal(ok[sure], ok_ref[sure]) and np.array_equal(first[sure], first_ref[sure])
 
 
+def test_edge_check_in_two_halves_equals_the_blocking_call():
+    model, params, boxes, s1, s2, nd = common.config4(n_edges=500)
+    eng = mp.Engine(model, boxes, params)
+    ok, first = eng.check_motion_batch(s1, s2, nd)[:2]
+    eng.check_motion_batch_begin(s1, s2, nd)
+    ok2, first2 = eng.check_motion_batch_end()
+    assert np.array_equal(ok, ok2) and np.array_equal(first, first2)
+    with pytest.raises(mp.MvkError):      # nothing in flight
+        eng.check_motion_batch_end()
+    eng.check_motion_batch_begin(s1, s2, nd)
+    with pytest.raises(mp.MvkError):      # one begin at a time
+        eng.check_motion_batch_begin(s1, s2, nd)
+    ok3, first3 = eng.check_motion_batch_end()
+    assert np.array_equal(ok, ok3) and np.array_equal(first, first3)
+    eng.close()
+
+
 # ---------------------------------------------------------------------------
 # BASELINE sizes: size-independent properties (the oracle cannot sweep 1M samples in seconds)
 # ---------------------------------------------------------------------------
