@@ -79,6 +79,9 @@ struct Tree {
 
 // A few persistent worker threads for the nearest-neighbour searches of a batch: with the validity
 // checks on the GPU, the linear scans over the trees are what is left on the host's critical path.
+// A search is issued every few tens of microseconds during a solve, and a condition-variable wake-up
+// costs about as much as the search itself, so the workers spin for a short while after each job
+// (and the caller spins for the completion) before they go back to sleep.
 class Workers {
  public:
   static Workers& get() {
@@ -92,62 +95,74 @@ class Workers {
       for (int k = 0; k < n; ++k) fn(k);
       return;
     }
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn;
-      n_ = n;
-      next_.store(0);
-      pending_ = static_cast<int>(th_.size());
-      ++epoch_;
+    // The job description lives in the slot of the epoch's parity: a worker that is one epoch late
+    // still reads its own epoch's description, and its compare-exchange on the ticket then fails.
+    const uint64_t epoch = (ticket_.load(std::memory_order_relaxed) >> 32) + 1;
+    fn_[epoch & 1].store(&fn, std::memory_order_relaxed);
+    n_[epoch & 1].store(n, std::memory_order_relaxed);
+    done_.store(0, std::memory_order_relaxed);
+    ticket_.store(epoch << 32, std::memory_order_release);  // job counter in the low half
+    if (sleepers_.load(std::memory_order_acquire) > 0) {
+      { std::lock_guard<std::mutex> lk(m_); }
+      cv_.notify_all();
     }
-    cv_.notify_all();
-    for (int k; (k = next_.fetch_add(1)) < n;) fn(k);
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [&] { return pending_ == 0; });
-    fn_ = nullptr;
+    work(epoch, &fn, n);
+    while (done_.load(std::memory_order_acquire) != n) cpu_relax();
   }
 
  private:
+  static void cpu_relax() { __builtin_ia32_pause(); }
+  // take jobs of `epoch` until none is left (or the epoch has moved on: a late worker does nothing)
+  void work(uint64_t epoch, const std::function<void(int)>* fn, int n) {
+    for (;;) {
+      uint64_t t = ticket_.load(std::memory_order_acquire);
+      if ((t >> 32) != epoch || static_cast<int>(t & 0xffffffffu) >= n) return;
+      if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
+      (*fn)(static_cast<int>(t & 0xffffffffu));
+      done_.fetch_add(1, std::memory_order_release);
+    }
+  }
   Workers() {
     unsigned hw = std::thread::hardware_concurrency();
     int n = hw > 2 ? static_cast<int>(hw > 16 ? 8 : hw / 2) - 1 : 0;
+    if (const char* e = std::getenv("MVK_PLAN_THREADS")) {  // total threads taking part, the caller included
+      const int want = std::atoi(e);
+      if (want >= 1 && want <= 64) n = want - 1;
+    }
     for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
   }
   ~Workers() {
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      stop_ = true;
-      ++epoch_;
-    }
+    stop_.store(true, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk(m_); }
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
   void loop() {
     uint64_t seen = 0;
     for (;;) {
-      const std::function<void(int)>* fn;
-      int n;
-      {
+      // wait for a new epoch: spin for about 200 us, then sleep
+      int spins = 0;
+      while ((ticket_.load(std::memory_order_acquire) >> 32) == seen && !stop_.load(std::memory_order_acquire)) {
+        if (++spins < 20000) { cpu_relax(); continue; }
         std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return epoch_ != seen; });
-        seen = epoch_;
-        if (stop_) return;
-        fn = fn_;
-        n = n_;
+        sleepers_.fetch_add(1, std::memory_order_acq_rel);
+        cv_.wait(lk, [&] { return (ticket_.load(std::memory_order_acquire) >> 32) != seen || stop_.load(std::memory_order_acquire); });
+        sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+        spins = 0;
       }
-      for (int k; (k = next_.fetch_add(1)) < n;) (*fn)(k);
-      std::lock_guard<std::mutex> lk(m_);
-      if (--pending_ == 0) done_.notify_one();
+      if (stop_.load(std::memory_order_acquire)) return;
+      seen = ticket_.load(std::memory_order_acquire) >> 32;
+      work(seen, fn_[seen & 1].load(std::memory_order_relaxed), n_[seen & 1].load(std::memory_order_relaxed));
     }
   }
   std::vector<std::thread> th_;
   std::mutex m_;
-  std::condition_variable cv_, done_;
-  const std::function<void(int)>* fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_ = 0, pending_ = 0;
-  uint64_t epoch_ = 0;
-  bool stop_ = false;
+  std::condition_variable cv_;
+  std::atomic<const std::function<void(int)>*> fn_[2] = {{nullptr}, {nullptr}};
+  std::atomic<int> n_[2] = {{0}, {0}};
+  std::atomic<int> done_{0}, sleepers_{0};
+  std::atomic<uint64_t> ticket_{0};  // epoch << 32 | next job
+  std::atomic<bool> stop_{false};
 };
 
 // uniform sample of the planner's space (OMPL's default samplers: box-uniform

@@ -3,7 +3,7 @@
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
 States are independent, so the data path has NO collective: rank r evaluates the contiguous index range
 shard_range(n, r, world).  The only exchanges are
-  * all-gather of the packed validity bit mask (n/8 bytes in total), and
+  * all-gather of the packed validity bit mask (n/8 bytes in total), or of the per-edge verdicts, and
   * all-reduce of the few scalars of mvk_stats (sum of counts, min/max with arg via a gathered table).
 """
 import numpy as np
@@ -34,6 +34,28 @@ def gather_masks(local_mask, n, group=None):
     full = torch.empty(world * per, dtype=torch.int64, device=local_mask.device)
     dist.all_gather_into_tensor(full, buf, group=group)
     return full[: (n + 63) // 64]
+
+
+def shard_edges(n_edges, rank, world):
+    """Contiguous shard [lo, hi) of a batch of edges (config c4): edges shard by edge, never by step, so an
+    edge's first_invalid needs no cross-rank reduction."""
+    per = (n_edges + world - 1) // world
+    return min(n_edges, rank * per), min(n_edges, (rank + 1) * per)
+
+
+def gather_edge_verdicts(local_ok, local_first, n_edges, group=None):
+    """local_ok uint8 [hi-lo], local_first int32 [hi-lo] of this rank's shard_edges range.  Returns (ok, first)
+    for all n_edges on every rank: one all-gather of 5 bytes per edge."""
+    world = dist.get_world_size(group)
+    per = (n_edges + world - 1) // world
+    dev = local_ok.device
+    buf = torch.zeros(per, 2, dtype=torch.int32, device=dev)
+    k = local_ok.numel()
+    buf[:k, 0] = local_ok.to(torch.int32)
+    buf[:k, 1] = local_first
+    full = torch.empty(world * per, 2, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(full, buf, group=group)
+    return full[:n_edges, 0].to(torch.uint8), full[:n_edges, 1].contiguous()
 
 
 _MIN_KEYS = ("min_dist", "min_margin", "min_thrust", "min_rp_position_margin")
