@@ -123,9 +123,15 @@ class Workers {
     }
   }
   Workers() {
+    // threads taking part, the caller included: half the CPUs this process may use (OMP_NUM_THREADS when
+    // set: a container's share of a bigger machine), at most 16; MVK_PLAN_THREADS overrides
     unsigned hw = std::thread::hardware_concurrency();
-    int n = hw > 2 ? static_cast<int>(hw > 16 ? 8 : hw / 2) - 1 : 0;
-    if (const char* e = std::getenv("MVK_PLAN_THREADS")) {  // total threads taking part, the caller included
+    if (const char* e = std::getenv("OMP_NUM_THREADS")) {
+      const int v = std::atoi(e);
+      if (v >= 1 && static_cast<unsigned>(v) < hw) hw = static_cast<unsigned>(v);
+    }
+    int n = hw > 2 ? static_cast<int>(hw > 32 ? 16 : hw / 2) - 1 : 0;
+    if (const char* e = std::getenv("MVK_PLAN_THREADS")) {
       const int want = std::atoi(e);
       if (want >= 1 && want <= 64) n = want - 1;
     }
