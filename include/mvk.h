@@ -392,7 +392,7 @@ typedef struct mvk_plan_result {
   int32_t n_waypoints;
   double solve_ms;      /* wall time of the search (planning_time of the log, in ms) */
   double path_length;   /* sum of space distances along the way-points (motion_cost) */
-  uint64_t iterations, state_checks, edge_checks, edge_steps;
+  uint64_t iterations, state_checks, edge_checks, edge_steps; /* edges / interpolation steps submitted to the checker */
   int32_t tree_sizes[2];
 } mvk_plan_result;
 

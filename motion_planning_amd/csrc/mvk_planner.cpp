@@ -9,10 +9,11 @@
 // two trees rooted at start and goal, EXTEND toward a uniform sample by at most
 // `range`, then CONNECT the other tree greedily toward the new node, swap.
 // What is MI355X-shaped about it: validity is never asked one state at a time.
-// Each iteration proposes `batch` extensions and sends them to ONE edge-check
-// launch; the connect step is ONE more launch whose first_invalid output says how
-// far each straight connection got (the greedy repeat-extend of RRT-Connect
-// collapses into "advance to the last valid interpolation step").
+// Each iteration proposes `batch` extensions and sends them, TOGETHER with the
+// connect edge of every proposal, to ONE edge-check launch; the first_invalid
+// output of a connect edge says how far the straight connection got (the greedy
+// repeat-extend of RRT-Connect collapses into "advance to the last valid
+// interpolation step").
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -370,6 +371,9 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
   std::vector<int> from_idx, near_a, near_idx, near_conn, fresh;
   std::vector<double> samples, targets, dist_a, dist_conn;
   bool have_next = false;  // samples / near_a / dist_a already hold the coming iteration's batch
+  const bool merged = ck->check_motions_begin != nullptr && ck->check_motions_end != nullptr;
+  std::vector<uint8_t> conn_ok, ext_ok;
+  std::vector<int32_t> conn_first, conn_nd;
   // nearest node of `t` among nodes b0.. for each of n query states (row-major); `merge` keeps an
   // earlier result when it is at least as close (ties go to the lower index, as one scan would)
   auto search_all = [&](const Tree& t, int b0, const double* q, int n, std::vector<int>& idx, std::vector<double>& dst, bool merge) {
@@ -399,13 +403,18 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
     ++out->iterations;
     Tree& ta = tree[cur];
     Tree& tb = tree[1 - cur];
-    // ---- EXTEND: `batch` independent samples, one launch -------------------
+    // ---- EXTEND and CONNECT in one launch -------------------------------------------------
+    // Proposal e is the extension ta[from_idx[e]] -> target_e.  Its connect edge, the straight shot
+    // from the other tree's nearest node to target_e, only matters if the extension is valid, but it
+    // does not depend on the verdict: both edges go into the SAME launch (edges e and n_prop + e), and
+    // the verdicts of connect edges whose extension failed are ignored.  A call costs the same up
+    // to about a thousand edges, so this halves the GPU round trips of an iteration.
     from.clear();
     to.clear();
     from_idx.clear();
     auto tA = now();
     targets.resize(static_cast<size_t>(batch) * dim);
-    if (!have_next) {  // (otherwise drawn and searched while the last connect check was in flight)
+    if (!have_next) {  // (otherwise drawn and searched while the last check was in flight)
       samples.resize(static_cast<size_t>(batch) * dim);
       for (int k = 0; k < batch; ++k) sample_uniform(p, J, rng, samples.data() + static_cast<size_t>(k) * dim);
       t_sample += since(tA); tA = now();
@@ -425,67 +434,85 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
       to.push_back(tgt);
     }
     if (to.empty()) continue;
+    const size_t n_prop = to.size();
+    t_pack += since(tA); tA = now();
+    search_all(tb, 0, targets.data(), static_cast<int>(n_prop), near_conn, dist_conn, false);
+    t_near += since(tA); tA = now();
     for (int ni : from_idx) from.push_back(ta.at(ni));
-    eb.pack(from, to, p, J);
-    t_pack += since(tA); tA = now();
-    if (int rc = check_begin(to.size())) return rc;
-    // while the check is in flight: where every proposed node would connect to in the other tree
-    const int n_prop = static_cast<int>(to.size());
-    search_all(tb, 0, targets.data(), n_prop, near_conn, dist_conn, false);
-    t_near += since(tA); tA = now();
-    if (int rc = check_end(to.size())) return rc;
-    t_check += since(tA); tA = now();
-    out->edge_checks += to.size();
-    for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
-    fresh.clear();
-    near_idx.clear();
-    for (size_t e = 0; e < to.size(); ++e)
-      if (eb.ok[e]) {
-        fresh.push_back(ta.add(to[e], from_idx[e]));
-        near_idx.push_back(near_conn[e]);
-      }
-    t_tree += since(tA); tA = now();
-    if (fresh.empty()) { cur = 1 - cur; continue; }
-    // ---- CONNECT: straight shots from the other tree toward every fresh node ----
-    from.clear();
-    to.clear();
-    // (the trees only grow after the check below, so pointers into them stay valid while it runs)
-    for (int fi : fresh) to.push_back(ta.at(fi));
-    for (int ni : near_idx) from.push_back(tb.at(ni));
-    eb.pack(from, to, p, J);
-    t_pack += since(tA); tA = now();
-    if (int rc = check_begin(fresh.size())) return rc;
-    // while the check is in flight: the next iteration extends tb -- draw its samples and search
-    // tb as it stands; the nodes this connect adds are searched afterwards
     const int tb_before = tb.size();
-    samples.resize(static_cast<size_t>(batch) * dim);
-    for (int k = 0; k < batch; ++k) sample_uniform(p, J, rng, samples.data() + static_cast<size_t>(k) * dim);
-    t_sample += since(tA); tA = now();
-    search_all(tb, 0, samples.data(), batch, near_a, dist_a, false);
-    t_near += since(tA); tA = now();
-    if (int rc = check_end(fresh.size())) return rc;
-    t_check += since(tA); tA = now();
-    out->edge_checks += fresh.size();
-    for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
-    for (size_t e = 0; e < fresh.size() && !solved; ++e) {
-      if (eb.ok[e]) {
-        link[cur] = fresh[e];
-        link[1 - cur] = tb.add(ta.at(fresh[e]), near_idx[e]);
+    if (merged) {
+      for (size_t e = 0; e < n_prop; ++e) {
+        const double* tgt = to[e];
+        from.push_back(tb.at(near_conn[e]));
+        to.push_back(tgt);
+      }
+      eb.pack(from, to, p, J);
+      t_pack += since(tA); tA = now();
+      if (int rc = check_begin(2 * n_prop)) return rc;
+      // while the check is in flight: the next iteration extends tb -- draw its samples and search
+      // tb as it stands; the nodes this iteration adds to it are searched afterwards
+      samples.resize(static_cast<size_t>(batch) * dim);
+      for (int k = 0; k < batch; ++k) sample_uniform(p, J, rng, samples.data() + static_cast<size_t>(k) * dim);
+      t_sample += since(tA); tA = now();
+      search_all(tb, 0, samples.data(), batch, near_a, dist_a, false);
+      t_near += since(tA); tA = now();
+      if (int rc = check_end(2 * n_prop)) return rc;
+      t_check += since(tA); tA = now();
+      out->edge_checks += 2 * n_prop;
+      for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
+      conn_ok.assign(eb.ok.begin() + n_prop, eb.ok.end());
+      conn_first.assign(eb.first.begin() + n_prop, eb.first.end());
+      conn_nd.assign(eb.nd.begin() + n_prop, eb.nd.end());
+    } else {
+      // a blocking checker (the CPU one): two calls, the connect edges of the valid extensions only
+      eb.pack(from, to, p, J);
+      t_pack += since(tA); tA = now();
+      if (int rc = check_end(n_prop)) return rc;
+      t_check += since(tA); tA = now();
+      out->edge_checks += n_prop;
+      for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
+      ext_ok.assign(eb.ok.begin(), eb.ok.end());
+      from.clear();
+      std::vector<const double*> cto;
+      std::vector<size_t> which;
+      for (size_t e = 0; e < n_prop; ++e)
+        if (ext_ok[e]) { from.push_back(tb.at(near_conn[e])); cto.push_back(to[e]); which.push_back(e); }
+      conn_ok.assign(n_prop, 0);
+      conn_first.assign(n_prop, 0);
+      conn_nd.assign(n_prop, 1);
+      if (!which.empty()) {
+        eb.pack(from, cto, p, J);
+        t_pack += since(tA); tA = now();
+        if (int rc = check_end(which.size())) return rc;
+        t_check += since(tA); tA = now();
+        out->edge_checks += which.size();
+        for (int32_t c : eb.nd) out->edge_steps += static_cast<uint64_t>(c);
+        for (size_t i = 0; i < which.size(); ++i) { conn_ok[which[i]] = eb.ok[i]; conn_first[which[i]] = eb.first[i]; conn_nd[which[i]] = eb.nd[i]; }
+      }
+      eb.ok.assign(ext_ok.begin(), ext_ok.end());
+    }
+    for (size_t e = 0; e < n_prop && !solved; ++e) {
+      if (!eb.ok[e]) continue;  // the extension is invalid (merged: its connect edge was checked for nothing)
+      const int fi = ta.add(to[e], from_idx[e]);
+      if (conn_ok[e]) {
+        link[cur] = fi;
+        link[1 - cur] = tb.add(ta.at(fi), near_conn[e]);
         solved = true;
-      } else if (eb.first[e] > 1) {
+      } else if (conn_first[e] > 1) {
         // trapped part-way: keep the last valid interpolation step as a new node
         std::vector<double> adv(dim);
-        const double t = static_cast<double>(eb.first[e] - 1) / static_cast<double>(eb.nd[e]);
-        const std::vector<double> nb(tb.at(near_idx[e]), tb.at(near_idx[e]) + dim);
-        mvk_space_interpolate(&p, J, nb.data(), ta.at(fresh[e]), t, adv.data());
-        tb.add(adv.data(), near_idx[e]);
+        const double t = static_cast<double>(conn_first[e] - 1) / static_cast<double>(conn_nd[e]);
+        const std::vector<double> nb(tb.at(near_conn[e]), tb.at(near_conn[e]) + dim);
+        mvk_space_interpolate(&p, J, nb.data(), ta.at(fi), t, adv.data());
+        tb.add(adv.data(), near_conn[e]);
       }
     }
     t_tree += since(tA); tA = now();
-    if (!solved && tb.size() > tb_before) search_all(tb, tb_before, samples.data(), batch, near_a, dist_a, true);
-    have_next = true;
+    if (merged) {
+      if (!solved && tb.size() > tb_before) search_all(tb, tb_before, samples.data(), batch, near_a, dist_a, true);
+      have_next = true;
+    }
     t_near += since(tA); tA = now();
-    t_tree += since(tA);
     cur = 1 - cur;
   }
   out->solve_ms = elapsed_ms();

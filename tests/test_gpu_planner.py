@@ -51,4 +51,6 @@ def test_same_seed_same_plan_on_gpu_and_cpu_checkers():
     b, ib = PL.plan_rrt_connect_cb(params, 3, cs, cm, start, goal, time_limit_s=60.0, seed=11, batch=8)
     assert a is not None and b is not None
     assert a.shape == b.shape and np.array_equal(a, b)
-    assert ia["iterations"] == ib["iterations"] and ia["edge_checks"] == ib["edge_checks"]
+    # same search; the GPU run checks every proposal's connect edge in the same launch as its extension (also the
+    # ones whose extension turns out invalid), the blocking CPU checker is only asked for the ones that matter
+    assert ia["iterations"] == ib["iterations"] and ia["edge_checks"] >= ib["edge_checks"]
