@@ -2,13 +2,14 @@
 //
 // One lane = one state (a sample of a SoA batch, or one interpolation step of
 // an edge).  The path is fp64 VALU bound: a state costs
-// kiloflops of arithmetic against ~100 B of HBM traffic, so the design goals
-// are (1) no per-lane memory beyond the coalesced SoA row reads, (2) wave-uniform
-// data (model constants, obstacle boxes) fetched through scalar loads so it
-// lives in SGPRs and costs no VGPRs or LDS bandwidth, (3) divergence-free
-// broadphase sweeps with the rare exact narrowphase deferred to per-lane LDS
-// candidate lists and run once per primitive, where the primitive kind is
-// wave-uniform.
+// kiloflops of arithmetic against ~100 B of HBM traffic.  Shape of the flag path
+// (the headline): screen_kernel = model update + statics in fp64, then an fp32
+// screen of the few boxes the broadphase grid lists near each chain segment,
+// shared out over the wave through an LDS ring; the states it cannot decide are
+// handed (state index + a compact record) to exact_kernel, which runs the fp64
+// narrowphase one (primitive, box) pair per lane.  Wave-uniform data (model
+// constants) comes through scalar loads; the full / avoidance kernels are the
+// all-boxes correctness path with per-lane LDS candidate lists.  DESIGN.md 4-5.
 //
 // What one state evaluation computes (V-spec), replacing
 //   MotionPlanning::isStateValid            sampling_based_method/src/motion_planning.cpp:76-164
@@ -19,9 +20,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
-#include <type_traits>
-
 #include <cstring>
+#include <type_traits>
 
 #include "mvk_internal.h"
 
