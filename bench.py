@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
     ap.add_argument("--no-edges", action="store_true")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="one rank: run the step's RCCL exchange (a group of one) exactly as the N > 1 path issues it")
     args = ap.parse_args()
 
     import torch
@@ -213,8 +215,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    exchange = world > 1 or args.rehearse_exchange
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.workload == "c4":
@@ -241,44 +245,68 @@ def main():
     eng.set_profiling(True)   # HIP events on the launch stream around each kernel of a call
     d_soa = torch.from_numpy(w.soa).to(dev)   # (c5: unused, the sweep reads no input)
     words = (n + 63) // 64
-    d_mask = torch.zeros(words, dtype=torch.int64, device=dev)
-    d_all = torch.zeros(world * words, dtype=torch.int64, device=dev) if world > 1 else None
-    d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    # Two sets of exchange buffers: the mask all-gather and the count all-reduce of step k run on RCCL's stream
+    # while the kernels of step k+1 fill the other set (collectives overlapped with compute).
+    n_slot = 2 if exchange else 1
+    d_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(n_slot)]
+    d_alls = [torch.zeros(world * words, dtype=torch.int64, device=dev) for _ in range(n_slot)] if exchange else None
+    d_cnts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n_slot)]
+    d_mask = d_masks[0]
 
     sweep = args.workload == "c5"   # config 5: states generated in the kernel from the sample index, rank r sweeps [r*n, (r+1)*n)
     sweep_pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
 
-    def run_batch():
+    def run_batch(mask):
         if sweep:
-            eng.sweep_mask_dev(sweep_pose, rank * n, n, common.SEED0 + 5, d_mask)
+            eng.sweep_mask_dev(sweep_pose, rank * n, n, common.SEED0 + 5, mask)
         else:
-            eng.is_valid_mask_dev(d_soa, w.layout, d_mask)
+            eng.is_valid_mask_dev(d_soa, w.layout, mask)
 
-    def step():
-        run_batch()
-        if world > 1:
-            eng.mask_count_dev(d_mask, n, d_cnt)
-            dist.all_gather_into_tensor(d_all, d_mask)
-            dist.all_reduce(d_cnt)
+    main_stream = torch.cuda.current_stream()
+    side = torch.cuda.Stream(device=dev) if exchange else None   # the exchange's own stream: count kernel + RCCL calls
+    done = [None] * n_slot
 
-    for _ in range(args.warmup):
-        step()
+    def step(k, ev=None):
+        slot = k % n_slot
+        if done[slot] is not None:    # this set's last exchange (step k-2) must be through before it is refilled
+            main_stream.wait_event(done[slot])   # (a stream dependency, the host does not block)
+        if ev:
+            ev[0].record()
+        run_batch(d_masks[slot])
+        if ev:
+            ev[1].record()
+        if exchange:
+            ready = torch.cuda.Event()
+            ready.record(main_stream)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                eng.mask_count_dev(d_masks[slot], n, d_cnts[slot])
+                works = (dist.all_gather_into_tensor(d_alls[slot], d_masks[slot], async_op=True),
+                         dist.all_reduce(d_cnts[slot], async_op=True))
+                for wk in works:
+                    wk.wait()
+                done[slot] = torch.cuda.Event()
+                done[slot].record(side)
+
+    def drain():
+        for slot in range(n_slot):
+            if done[slot] is not None:
+                main_stream.wait_event(done[slot])
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if exchange:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        run_batch()
-        ev[k][1].record()
-        if world > 1:
-            eng.mask_count_dev(d_mask, n, d_cnt)
-            dist.all_gather_into_tensor(d_all, d_mask)
-            dist.all_reduce(d_cnt)
+        step(k, ev[k])
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if exchange:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -286,11 +314,11 @@ def main():
     # per-kernel split of a call (library events on the same stream), sampled outside the timed region
     split = []
     for _ in range(min(args.steps, 10)):
-        run_batch()
+        run_batch(d_mask)
         split.append(eng.last_kernel_ms())
     screen_ms = float(np.mean([x[0] for x in split]))
     exact_ms = float(np.mean([x[1] for x in split]))
-    if world > 1:
+    if exchange:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -337,8 +365,10 @@ def main():
                          "pmc_source": (pmc or {}).get("source")},
             "valid_in_first_4096_words": valid,
         }
-        if world > 1:
-            out["valid_total_last_step"] = int(d_cnt.item())   # all-reduced over ranks (mvk_mask_count_dev + RCCL sum)
+        if exchange:
+            last = (args.steps - 1) % n_slot
+            out["valid_total_last_step"] = int(d_cnts[last].item())   # all-reduced over ranks (mvk_mask_count_dev + RCCL sum)
+            out["exchange"] = "per step: all-gather of the packed mask + all-reduce of the valid count, overlapped with the next step's kernels"
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w)
         if not args.no_planner and world == 1:
@@ -347,7 +377,7 @@ def main():
             out["edge_checks"] = edge_checks(dev)
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 
