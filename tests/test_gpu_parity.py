@@ -301,6 +301,22 @@ def test_edge_check_in_two_halves_equals_the_blocking_call():
     eng.close()
 
 
+def test_two_contexts_interleaved_and_batch_sizes_shrinking_and_growing():
+    """Two engines (different robots, different scenes) alive at once with their calls interleaved, and one engine
+    fed batches of changing size: the hand-off buffers and counters are per context and carry nothing over."""
+    wa, wb = common.config2(n=6000), common.config3(n=3000)
+    ra = O.eval_batch(wa.model, wa.boxes, wa.params, wa.soa, wa.layout, threads=8)
+    rb = O.eval_batch(wb.model, wb.boxes, wb.params, wb.soa, wb.layout, threads=8)
+    ea, eb = mp.Engine(wa.model, wa.boxes, wa.params), mp.Engine(wb.model, wb.boxes, wb.params)
+    for n_a, n_b in ((6000, 3000), (130, 2999), (6000, 64), (1, 3000), (4097, 1025)):
+        fa = ea.is_valid_batch(wa.soa[:, :n_a], wa.layout)["flags"]
+        fb = eb.is_valid_batch(wb.soa[:, :n_b], wb.layout)["flags"]
+        assert not np.any((fa != ra["flags"][:n_a]) & ~ra["band"][:n_a].astype(bool)), (n_a, n_b)
+        assert not np.any((fb != rb["flags"][:n_b]) & ~rb["band"][:n_b].astype(bool)), (n_a, n_b)
+    ea.close()
+    eb.close()
+
+
 # ---------------------------------------------------------------------------
 # BASELINE sizes: size-independent properties (the oracle cannot sweep 1M samples in seconds)
 # ---------------------------------------------------------------------------
