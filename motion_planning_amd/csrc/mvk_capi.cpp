@@ -821,9 +821,11 @@ namespace {
 // d_edge_off: exclusive prefix of clamp(nd,1) (device), total = number of steps
 int run_edges_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_edges, size_t ld,
                   const int32_t* d_nd, const int64_t* d_edge_off, uint64_t total, int32_t nd_uniform,
-                  uint8_t* d_ok, int32_t* d_first, hipStream_t s, bool first_is_initialised = false) {
+                  uint8_t* d_ok, int32_t* d_first, hipStream_t s, bool first_is_initialised = false,
+                  const uint32_t* d_edge_block = nullptr) {
   EvalArgs a;
   base_args(c, a);
+  a.edge_block = d_edge_block;
   a.s1 = d_s1;
   a.s2 = d_s2;
   a.nd = d_nd;
@@ -905,8 +907,12 @@ extern "C" int mvk_check_motion_batch_begin(mvk_ctx* c, const double* s1, const 
   // the verdict comes back with one copy (ok is derived from first_invalid on the host).
   const size_t rows = static_cast<size_t>(space_dim(&c->params, c->model.n_joint));
   const size_t dld = round_up(n_edges, 64);
+  size_t steps_max = 0;  // upper bound of the lane count, for the size of the per-block hints
+  if (nd) for (size_t e = 0; e < n_edges; ++e) steps_max += static_cast<size_t>(nd[e] < 1 ? 1 : nd[e]);
+  const size_t n_blk = nd ? (steps_max + kBlock - 1) / kBlock : 0;
   const size_t off_s2 = rows * dld * sizeof(double), off_off = 2 * off_s2, off_nd = off_off + dld * sizeof(int64_t),
-               off_first = off_nd + dld * sizeof(int32_t), bytes = off_first + dld * sizeof(int32_t);
+               off_first = off_nd + dld * sizeof(int32_t), off_blk = off_first + dld * sizeof(int32_t),
+               bytes = off_blk + round_up(n_blk, 64) * sizeof(uint32_t);
   if (int rc = c->pin_up.reserve(bytes)) return rc;
   if (int rc = c->pin_down.reserve(dld * sizeof(int32_t))) return rc;
   if (int rc = c->edge_blob.reserve(bytes)) return rc;
@@ -929,12 +935,22 @@ extern "C" int mvk_check_motion_batch_begin(mvk_ctx* c, const double* s1, const 
     hfirst[e] = v + 1;
     total += static_cast<uint64_t>(v);
   }
+  if (nd) {  // the edge holding the first lane of every block of kBlock lanes (saves the kernels a binary search)
+    uint32_t* hblk = reinterpret_cast<uint32_t*>(up + off_blk);
+    size_t e = 0;
+    for (size_t b = 0; b < n_blk; ++b) {
+      const int64_t lane = static_cast<int64_t>(b * kBlock);
+      while (e + 1 < n_edges && hoff[e + 1] <= lane) ++e;
+      hblk[b] = static_cast<uint32_t>(e);
+    }
+  }
   char* dev = static_cast<char*>(c->edge_blob.p);
   HIP_TRY(hipMemcpyAsync(dev, up, bytes, hipMemcpyHostToDevice, s));
   if (int rc = run_edges_dev(c, reinterpret_cast<const double*>(dev), reinterpret_cast<const double*>(dev + off_s2), n_edges, dld,
                              nd ? reinterpret_cast<const int32_t*>(dev + off_nd) : nullptr,
                              nd ? reinterpret_cast<const int64_t*>(dev + off_off) : nullptr, total, nu, nullptr,
-                             reinterpret_cast<int32_t*>(dev + off_first), s, /*first_is_initialised=*/true))
+                             reinterpret_cast<int32_t*>(dev + off_first), s, /*first_is_initialised=*/true,
+                             nd ? reinterpret_cast<const uint32_t*>(dev + off_blk) : nullptr))
     return rc;
   HIP_TRY(hipMemcpyAsync(c->pin_down.p, dev + off_first, n_edges * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   c->edges_in_flight = n_edges;

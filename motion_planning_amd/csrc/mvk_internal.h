@@ -90,6 +90,7 @@ struct EvalArgs {
   const double* s2;
   const int32_t* nd;         // per-edge segment counts or nullptr
   const int64_t* edge_off;   // exclusive prefix of nd (when nd != nullptr)
+  const uint32_t* edge_block;  // optional hint: the edge holding lane b * kBlock, per block b of lanes (else binary search from 0)
   int32_t nd_uniform;
   uint64_t n;   // samples (or total edge steps)
   uint64_t n_edges;

@@ -1232,6 +1232,17 @@ DEV void edge_step(const EvalArgs& A, uint64_t li, uint64_t& edge, int& step, in
     step = static_cast<int>(li - edge * nd_e) + 1;
   } else {
     uint64_t lo = 0, hi = A.n_edges;  // largest e with edge_off[e] <= li
+    if (A.edge_block) {
+      // the edge holding the first lane of this block of lanes, then a few steps forward: an edge of
+      // nd steps spans nd lanes, so the answer is usually within a handful of edges (two dependent
+      // loads instead of log2(n_edges))
+      lo = A.edge_block[li / kBlock];
+#pragma unroll 1
+      for (int it = 0; it < 8; ++it) {
+        if (lo + 1 >= A.n_edges || static_cast<uint64_t>(A.edge_off[lo + 1]) > li) { hi = lo + 1; break; }
+        ++lo;
+      }
+    }
     while (hi - lo > 1) {
       const uint64_t mid = (lo + hi) >> 1;
       if (static_cast<uint64_t>(A.edge_off[mid]) <= li) lo = mid; else hi = mid;
