@@ -717,8 +717,12 @@ DEV double point_box_dist2(const double t[3], const double h[3]) {
 
 // exact test of one primitive against one box (primitive kind is wave-uniform); t = primitive
 // centre in the box frame.  SIGNED: signed distance; otherwise only the sign is meaningful.
+// `cutoff` (SIGNED only): the caller keeps a running minimum; when the separating-axis bound of a box
+// pair, a lower bound of its distance, already reaches it, the exact edge-edge distance is skipped and
+// that bound is returned (>= cutoff, so the minimum is not affected).
 template <bool SIGNED>
-DEV double narrow(int type, const double PR[9], double d0, double d1, double d2, const DevObs& O, const double t[3]) {
+DEV double narrow(int type, const double PR[9], double d0, double d1, double d2, const DevObs& O, const double t[3],
+                  double cutoff = INFINITY) {
   double d;
   if (type == MVK_PRIM_CAPSULE) {
     // axis = local z in world = third column of PR, into the box frame
@@ -742,7 +746,7 @@ DEV double narrow(int type, const double PR[9], double d0, double d1, double d2,
     const double a[3] = {d0, d1, d2};
     if (SIGNED) {
       d = box_box_sat<true>(t, Rr, a, O.h);
-      if (d > 0.0) {
+      if (d > 0.0 && d < cutoff) {
         // exact separation: closest features always include a point on an edge
         double s2 = box_edges_to_box2(t, Rr, a, O.h);
         double Rt[9], tb[3];  // obstacle in the primitive's frame
@@ -1114,7 +1118,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
           const DevObs O = obs[ob];
           double t[3];
           to_box_frame(O, pc, t);
-          mind = fmin(mind, narrow<true>(type, PR, d0, d1, d2, O, t));
+          mind = fmin(mind, narrow<true>(type, PR, d0, d1, d2, O, t, mind));
         }
       }
     }
@@ -1126,7 +1130,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
 // signed distance of one primitive to one box with the nearest points (box frame): pr on the robot
 // primitive, pe on the box.  Points are NaN when the pair is in contact (distance <= 0).
 DEV double narrow_cp(int type, const double PR[9], double d0, double d1, double d2, const DevObs& O, const double t[3],
-                     double pr[3], double pe[3]) {
+                     double pr[3], double pe[3], double cutoff = INFINITY) {
   pr[0] = pr[1] = pr[2] = pe[0] = pe[1] = pe[2] = NAN;
   if (type != MVK_PRIM_BOX) {
     const double hl = type == MVK_PRIM_CAPSULE ? d1 : 0.0;
@@ -1152,7 +1156,7 @@ DEV double narrow_cp(int type, const double PR[9], double d0, double d1, double 
       Rr[3 * r + c] = fma(O.R[r], PR[c], fma(O.R[3 + r], PR[3 + c], O.R[6 + r] * PR[6 + c]));
   const double a[3] = {d0, d1, d2};
   double d = box_box_sat<true>(t, Rr, a, O.h);
-  if (!(d > 0.0)) return d;
+  if (!(d > 0.0) || d >= cutoff) return d;  // in contact, or the separating-axis bound cannot beat the caller's minimum
   double pa1[3], pb1[3], pa2[3], pb2[3];
   const double s1 = box_edges_to_box_cp2(t, Rr, a, O.h, pa1, pb1);  // pa1 on the robot, pb1 on the box
   double Rt[9], tb[3];  // the box in the primitive's frame
@@ -1851,7 +1855,7 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
           const DevObs O = obs[ob];
           double t[3], pr[3], pq[3];
           to_box_frame(O, pc, t);
-          const double d = narrow_cp(type, PR, d0, d1, d2, O, t, pr, pq);
+          const double d = narrow_cp(type, PR, d0, d1, d2, O, t, pr, pq, best);
           if (d < best) {  // ascending box order, strict: the first minimum wins, as in the oracle
             best = d;
             bi = ob;
