@@ -364,6 +364,7 @@ int prepare_queue(mvk_ctx* c, EvalArgs& a, uint64_t n) {
 int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
                  uint64_t* d_mask, double* d_min_dist, double* d_margin, uint8_t* d_band,
                  const mvk_detail_out* det, bool force_full, hipStream_t s) {
+  if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
   if (n == 0) return MVK_OK;
   if (!d_soa || ld < n) return fail(MVK_ERR_INVALID_ARG, "bad state array (null, or ld < n)");
@@ -532,6 +533,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
 }
 
 extern "C" int mvk_set_scene(mvk_ctx* c, const mvk_box* boxes, size_t n_boxes) {
+  if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -539,6 +541,7 @@ extern "C" int mvk_set_scene(mvk_ctx* c, const mvk_box* boxes, size_t n_boxes) {
 }
 
 extern "C" int mvk_set_params(mvk_ctx* c, const mvk_params* p) {
+  if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c || !p) return fail(MVK_ERR_INVALID_ARG, "null argument");
   if (int rc = check_params(&c->model, p)) return rc;
   c->params = *p;
@@ -594,6 +597,7 @@ extern "C" int mvk_is_valid_mask_dev(mvk_ctx* c, const double* d_soa, size_t n, 
 
 extern "C" int mvk_sweep_mask_dev(mvk_ctx* c, const double* root_pose7, uint64_t first_index, size_t n, uint64_t seed,
                                   uint64_t* d_mask, void* stream) {
+  if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c || !root_pose7 || !d_mask) return fail(MVK_ERR_INVALID_ARG, "null argument");
   if (n == 0) return MVK_OK;
   HIP_TRY(hipSetDevice(c->device));
@@ -759,6 +763,7 @@ extern "C" int mvk_avoid_params_default(mvk_avoid_params* p) {
 
 extern "C" int mvk_collision_avoidance_batch_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout,
                                                  const mvk_avoid_params* prm, const mvk_avoid_out* o, void* stream) {
+  if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c || !prm || !o) return fail(MVK_ERR_INVALID_ARG, "null argument");
   if (n == 0) return MVK_OK;
   if (!d_soa || ld < n) return fail(MVK_ERR_INVALID_ARG, "bad state array (null, or ld < n)");
@@ -860,6 +865,7 @@ int prefix_counts(const int32_t* nd, size_t n, std::vector<int64_t>& off, uint64
 extern "C" int mvk_check_motion_batch_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_edges,
                                           size_t ld, const int32_t* d_nd, int32_t nd_uniform, uint8_t* d_ok,
                                           int32_t* d_first_invalid, void* stream) {
+  if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
   if (n_edges == 0) return MVK_OK;
   if (!d_s1 || !d_s2 || ld < n_edges) return fail(MVK_ERR_INVALID_ARG, "bad edge arrays (null, or ld < n_edges)");

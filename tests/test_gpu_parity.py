@@ -296,6 +296,8 @@ def test_edge_check_in_two_halves_equals_the_blocking_call():
     eng.check_motion_batch_begin(s1, s2, nd)
     with pytest.raises(mp.MvkError):      # one begin at a time
         eng.check_motion_batch_begin(s1, s2, nd)
+    with pytest.raises(mp.MvkError):      # and no other work on the ctx until its end
+        eng.is_valid_batch(np.zeros((eng.state_dim(A.LAYOUT_POSE7), 4)))
     ok3, first3 = eng.check_motion_batch_end()
     assert np.array_equal(ok, ok3) and np.array_equal(first, first3)
     eng.close()
