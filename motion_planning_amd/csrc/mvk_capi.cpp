@@ -220,6 +220,7 @@ void derive_extras(const mvk_model* m, DevExtras* x) {
           T.gimbal_pos[T.np][a] = m->prim_frame[q] == MVK_FRAME_SEG ? 0.0 : m->rotor_pos[m->prim_rotor[q]][a];
         }
         T.prim_frame[T.np] = m->prim_frame[q];
+        if (m->prim_frame[q] != MVK_FRAME_SEG) T.pad = 1;
         ++T.np;
       }
     x->seg_sph[k][0] = c[0]; x->seg_sph[k][1] = c[1]; x->seg_sph[k][2] = c[2];

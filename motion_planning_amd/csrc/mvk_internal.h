@@ -42,7 +42,7 @@ struct SegTab {
   double sph[3];                        // centre of the segment's bounding sphere
   double prim_pos[kSegPrimMax][3];      // collision origins, in their frame
   double gimbal_pos[kSegPrimMax][3];    // gimbal centre carrying the primitive (frame != SEG)
-  int32_t axis, joint, np, pad;
+  int32_t axis, joint, np, pad;         // pad: 1 when a primitive of the segment rides on a gimbal frame
   int32_t prim_frame[kSegPrimMax + 1];  // MVK_FRAME_*
 };
 

@@ -974,7 +974,7 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
     unsigned gb, ge;
     grid_cell(A.grid, sc, live, gb, ge);
     double gcr = 1.0, gsr = 0.0, gcp = 1.0, gsp = 0.0;
-    if (S::kGimbal) gimbal_cs(R[6], R[7], R[8], gcr, gsr, gcp, gsp);
+    if (S::kGimbal && T.pad) gimbal_cs(R[6], R[7], R[8], gcr, gsr, gcp, gsp);  // (T.pad: some primitive here rides on a gimbal frame)
     float c[3 * kSegPrimMax];
 #pragma unroll
     for (int j = 0; j < kSegPrimMax; ++j) {
