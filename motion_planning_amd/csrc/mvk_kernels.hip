@@ -404,6 +404,19 @@ DEV void gimbal_cs(double zlx, double zly, double zlz, double& cr, double& sr, d
   sp = zlx * n;
 }
 
+// the same with Newton reciprocal square roots instead of sqrt and two divisions (collision walks)
+DEV void gimbal_cs_fast(double zlx, double zly, double zlz, double& cr, double& sr, double& cp, double& sp) {
+  const double rho2 = fma(zly, zly, zlz * zlz);
+  const bool deg = !(rho2 > 0.0);
+  const double ir = rsqrt_nr(rho2);
+  cr = deg ? 1.0 : zlz * ir;
+  sr = deg ? 0.0 : -zly * ir;
+  const double w = fma(-zly, sr, zlz * cr);
+  const double n = rsqrt_nr(fma(zlx, zlx, w * w));
+  cp = w * n;
+  sp = zlx * n;
+}
+
 // ------------------------------------------------------------------------
 // walk 1: FK, centre of gravity, rotor geometry, statics, stability margin
 // ------------------------------------------------------------------------
@@ -974,7 +987,7 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
     unsigned gb, ge;
     grid_cell(A.grid, sc, live, gb, ge);
     double gcr = 1.0, gsr = 0.0, gcp = 1.0, gsp = 0.0;
-    if (S::kGimbal && T.pad) gimbal_cs(R[6], R[7], R[8], gcr, gsr, gcp, gsp);  // (T.pad: some primitive here rides on a gimbal frame)
+    if (S::kGimbal && T.pad) gimbal_cs_fast(R[6], R[7], R[8], gcr, gsr, gcp, gsp);  // (T.pad: some primitive here rides on a gimbal frame)
     float c[3 * kSegPrimMax];
 #pragma unroll
     for (int j = 0; j < kSegPrimMax; ++j) {
