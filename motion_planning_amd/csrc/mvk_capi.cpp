@@ -167,6 +167,11 @@ int check_model_shape(const mvk_model* m) {
 void derive_extras(const mvk_model* m, DevExtras* x) {
   std::memset(x, 0, sizeof(*x));
   x->tan_edf_max_tilt = std::tan(m->edf_max_tilt);
+  {
+    double mass = 0.0;
+    for (int k = 0; k < m->n_seg; ++k) mass += m->seg_mass[k];
+    x->inv_mass = 1.0 / mass;
+  }
   int at = 0;
   for (int k = 0; k < m->n_seg; ++k) {
     x->seg_prim_begin[k] = at;

@@ -54,6 +54,7 @@ struct DevExtras {
   int32_t prim_order[MVK_MAX_PRIM];
   double seg_sph[MVK_MAX_SEG][4];  // per segment: sphere (centre in the segment frame, radius) holding its primitives
   double reach;                    // bound on the distance of any primitive point from the root origin
+  double inv_mass;                 // 1 / total mass
   SegTab seg_tab[MVK_MAX_SEG];
 };
 

@@ -130,7 +130,10 @@ DEV double excess_abs(double x, double h) { return fmax(fabs(x) - h, 0.0); }
 // tf::Matrix3x3::setRotation
 DEV void quat_to_mat(double x, double y, double z, double w, double R[9]) {
   const double d = x * x + y * y + z * z + w * w;
-  const double s = 2.0 / d;
+  double rd = __builtin_amdgcn_rcp(d);  // 1/d by Newton iteration (two steps: full precision) instead of a division
+  rd = rd * fma(-d, rd, 2.0);
+  rd = rd * fma(-d, rd, 2.0);
+  const double s = 2.0 * rd;
   const double xs = x * s, ys = y * s, zs = z * s;
   const double wx = w * xs, wy = w * ys, wz = w * zs;
   const double xx = x * xs, xy = x * ys, xz = x * zs;
@@ -498,7 +501,7 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
       }
     }
   });
-  const double inv_mass = 1.0 / mass;
+  const double inv_mass = X->inv_mass;  // = 1 / mass, from the host
 #pragma unroll
   for (int c = 0; c < 3; ++c) cog[c] *= inv_mass;
   if (A.cog) {
