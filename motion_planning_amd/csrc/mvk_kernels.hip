@@ -663,14 +663,18 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
   margin = fmin(margin, fmin(lam_min - M->thrust_min, M->thrust_max - lam_max));
   if (S::kGimbal) {
     const double tt = X->tan_edf_max_tilt, r2 = 2.0 * M->edf_radius;
+    bool clear = true;  // flag path: only the sign of the margin is observable, and h >= c <=> h^2 >= c^2 for c > 0
 #pragma unroll
     for (int a = 0; a < 2 * NL; ++a)
 #pragma unroll
       for (int b = a + 1; b < 2 * NL; ++b) {
         if (a / 2 == b / 2) continue;
         const double dx = E[a][0] - E[b][0], dy = E[a][1] - E[b][1], dz = E[a][2] - E[b][2];
-        margin = fmin(margin, sqrt(fma(dx, dx, dy * dy)) - fma(fabs(dz), tt, r2));
+        const double h2 = fma(dx, dx, dy * dy), c = fma(fabs(dz), tt, r2);
+        if (FULL) margin = fmin(margin, sqrt(h2) - c);
+        else clear = clear && (h2 >= c * c);
       }
+    if (!FULL && !clear) margin = -1.0;
   }
   if (singular) margin = -INFINITY;
   out.margin = margin;
