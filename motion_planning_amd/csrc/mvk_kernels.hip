@@ -596,6 +596,8 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
 #pragma unroll
   for (int i = 0; i < NL; ++i) { Vs[0] += V[i][0]; Vs[1] += V[i][1]; Vs[2] += V[i][2]; }
   double fc_t = INFINITY;
+  bool fc_t_ok = true, fc_rp_ok = true;
+  const double fc_t_thre2 = M->fc_t_min_thre * M->fc_t_min_thre, fc_rp_thre2 = M->fc_rp_min_thre * M->fc_rp_min_thre;
   // (not for the gimbal models: the branch costs their flag kernel more in spills than the block costs)
   if (FULL || S::kGimbal || M->fc_t_min_thre > 0.0) {
 #pragma unroll
@@ -606,8 +608,6 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
         const double ny = fma(V[i][2], V[j][0], -V[i][0] * V[j][2]);
         const double nz = fma(V[i][0], V[j][1], -V[i][1] * V[j][0]);
         const double n2 = fma(nx, nx, fma(ny, ny, nz * nz));
-        const double rn = rsqrt_nr1(n2);
-        const double sc = !(n2 * rn >= 1e-5) ? 0.0 : (0.5 * fmaxT) * rn;  // |n| < 1e-5 (n2 = 0 gives NaN): distance 0
         double sabs = 0.0;
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
@@ -615,7 +615,14 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
           sabs += fabs(fma(nx, V[k][0], fma(ny, V[k][1], nz * V[k][2])));
         }
         const double ssum = fma(nx, Vs[0], fma(ny, Vs[1], nz * Vs[2]));
-        fc_t = fmin(fc_t, fmax(sabs - fabs(ssum), 0.0) * sc);
+        const double dist_n = fmax(sabs - fabs(ssum), 0.0) * (0.5 * fmaxT);  // the distance times |n|
+        if (FULL) {
+          const double rn = rsqrt_nr1(n2);
+          fc_t = fmin(fc_t, !(n2 * rn >= 1e-5) ? 0.0 : dist_n * rn);  // |n| < 1e-5 (n2 = 0 gives NaN): distance 0
+        } else {
+          // flag path: only "distance >= threshold" is observable; squared, without the normalisation
+          fc_t_ok = fc_t_ok && (n2 >= 1e-10) && (dist_n * dist_n >= fc_t_thre2 * n2);
+        }
       }
   }
   // roll/pitch version: d_i = sum_j max(c_ij, 0) = (sum c_ij + sum |c_ij|) / 2, c_ij = (V_i x V_j)_z, c_ii = 0
@@ -623,8 +630,6 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const double na2 = fma(V[i][0], V[i][0], V[i][1] * V[i][1]);
-    const double ra = rsqrt_nr1(na2);
-    const double sc = !(na2 * ra >= 1e-5) ? 0.0 : (0.5 * fmaxT) * ra;
     double sabs = 0.0;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
@@ -632,7 +637,13 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
       sabs += fabs(fma(V[i][1], V[j][0], -V[i][0] * V[j][1]));
     }
     const double ssum = fma(V[i][1], Vs[0], -V[i][0] * Vs[1]);
-    fc_rp = fmin(fc_rp, fmax(sabs + ssum, 0.0) * sc);
+    const double dist_n = fmax(sabs + ssum, 0.0) * (0.5 * fmaxT);
+    if (FULL) {
+      const double ra = rsqrt_nr1(na2);
+      fc_rp = fmin(fc_rp, !(na2 * ra >= 1e-5) ? 0.0 : dist_n * ra);
+    } else {
+      fc_rp_ok = fc_rp_ok && (na2 >= 1e-10) && (dist_n * dist_n >= fc_rp_thre2 * na2);
+    }
   }
   out.fc_t_min = fc_t;
   out.fc_rp_min = fc_rp;
@@ -658,8 +669,13 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
 
   // stabilityCheck(): min slack over the active tests
   double margin = INFINITY;
-  if (M->fc_rp_min_thre > 0.0) margin = fmin(margin, fc_rp - M->fc_rp_min_thre);
-  if (M->fc_t_min_thre > 0.0) margin = fmin(margin, fc_t - M->fc_t_min_thre);
+  if (FULL) {
+    if (M->fc_rp_min_thre > 0.0) margin = fmin(margin, fc_rp - M->fc_rp_min_thre);
+    if (M->fc_t_min_thre > 0.0) margin = fmin(margin, fc_t - M->fc_t_min_thre);
+  } else {  // (the flag path sees only the sign of the margin)
+    if (M->fc_rp_min_thre > 0.0 && !fc_rp_ok) margin = -1.0;
+    if (M->fc_t_min_thre > 0.0 && !fc_t_ok) margin = -1.0;
+  }
   margin = fmin(margin, fmin(lam_min - M->thrust_min, M->thrust_max - lam_max));
   if (S::kGimbal) {
     const double tt = X->tan_edf_max_tilt, r2 = 2.0 * M->edf_radius;
