@@ -481,7 +481,8 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
       xform(R, p, M->rotor_pos[i][0], M->rotor_pos[i][1], M->rotor_pos[i][2], P[i]);
       if (S::kGimbal) {
         double cr, sr, cp, sp;
-        gimbal_cs(R[6], R[7], R[8], cr, sr, cp, sp);
+        if (FULL) gimbal_cs(R[6], R[7], R[8], cr, sr, cp, sp);
+        else gimbal_cs_fast(R[6], R[7], R[8], cr, sr, cp, sp);
         if (A.gimbal) {  // getGimbalProcessedJoint (multilink_state.cpp:136)
           A.gimbal[(2 * i) * A.ld + gi] = atan2(-R[7], R[8]);
           A.gimbal[(2 * i + 1) * A.ld + gi] = atan2(R[6], fma(-R[7], sr, R[8] * cr));
