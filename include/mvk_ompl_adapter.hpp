@@ -167,9 +167,10 @@ class StateValidityChecker
   virtual bool isValid(const ompl::base::State* state) const {
     double s[MVK_MAX_STATE_DIM];
     flatten_state(params_, n_joint_, state, s);
-    mvk_result r;
-    check(mvk_is_valid(ctx_, s, &r));
-    return r.valid != 0;
+    // the flag path (a batch of one): the verdict alone, without the distances mvk_is_valid also reports
+    std::uint8_t flag = 0;
+    check(mvk_is_valid_batch(ctx_, s, 1, 1, MVK_LAYOUT_OMPL, &flag, nullptr, nullptr, nullptr));
+    return flag != 0;
   }
 
   // batched isValid(states[N]): one kernel launch for all N states
