@@ -668,6 +668,23 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
   const size_t dld = round_up(n, 64);
   const int NL = c->model.n_rotor;
   if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
+  if (flags && !min_dist && !margin && !band && !det && !force_full && n <= (1u << 16)) {
+    // the verdicts of a small batch (down to the single state of an OMPL isValid call): shaped for latency
+    // like the edge checks -- the rows packed into one pinned block, one copy each way, one synchronisation
+    if (int rc = c->pin_up.reserve(dld * rows * sizeof(double))) return rc;
+    if (int rc = c->pin_down.reserve(dld)) return rc;
+    if (int rc = c->flags.reserve(dld)) return rc;
+    double* up = static_cast<double*>(c->pin_up.p);
+    for (int r = 0; r < rows; ++r) std::memcpy(up + static_cast<size_t>(r) * dld, soa + static_cast<size_t>(r) * ld, n * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(c->in_a.p, up, dld * rows * sizeof(double), hipMemcpyHostToDevice, s));
+    if (int rc = run_eval_dev(c, static_cast<const double*>(c->in_a.p), n, dld, layout, static_cast<uint8_t*>(c->flags.p), nullptr,
+                              nullptr, nullptr, nullptr, nullptr, false, s))
+      return rc;
+    HIP_TRY(hipMemcpyAsync(c->pin_down.p, c->flags.p, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(flags, c->pin_down.p, n);
+    return MVK_OK;
+  }
   if (int rc = copy_rows(c->in_a.p, dld, soa, ld, sizeof(double), n, rows, hipMemcpyHostToDevice, s)) return rc;
   if (flags) if (int rc = c->flags.reserve(dld)) return rc;
   if (band) if (int rc = c->band.reserve(dld)) return rc;
