@@ -98,7 +98,7 @@ struct mvk_ctx {
   DevExtras extras{};
   mvk_model* d_model = nullptr;
   DevExtras* d_extras = nullptr;
-  Buf obs, obsf, grid_start, grid_items;
+  Buf obs, obsf, grid_start, grid_items, dgrid_start, dgrid_items;
   // flag path hand-off between the screen and the exact stage (see EvalArgs).  Two alternating sets
   // of queue counters: call k appends to set k%2 and zeroes set (k+1)%2, so no memset sits between
   // launches.  Calls on one ctx must therefore be ordered with respect to each other (one stream at a time).
@@ -113,6 +113,8 @@ struct mvk_ctx {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool profiling = false, timed = false;
   GridDev grid{};
+  GridDev dgrid{};  // distance grid of the full path (start == nullptr: not in use for this scene)
+  double dgrid_radius = 0.0;
   int n_obs = 0;
   float f32_delta = 0.0f;
   double f32_range = 0.0;
@@ -262,6 +264,79 @@ int boxes_to_obs(const mvk_box* boxes, size_t n, std::vector<DevObs>& host) {
   return MVK_OK;
 }
 
+// Distance grid of the full path (minimum distances).  A primitive whose centre lies in a cell sees in
+// that cell's list every box within dgrid_radius = (largest primitive bounding radius + D) of the centre,
+// so whenever an upper bound U <= D of the state's distance is known, the cell list holds every box that
+// can realise the minimum for that primitive and the scan over all boxes is not needed.  D is read off
+// the scene: the 98th percentile of the distance from a point of the obstacles' bounding volume to the
+// nearest box (points farther than that fall back to the scan over all boxes).  Scenes where the lists
+// would not be much shorter than the whole set keep the scan (scalar loads at wave-uniform addresses).
+int upload_distance_grid(mvk_ctx* c, const std::vector<DevObs>& host) {
+  c->dgrid = GridDev{};
+  c->dgrid_radius = 0.0;
+  const size_t n = host.size();
+  if (n < 128) return MVK_OK;
+  double rb = 0.0;
+  for (int q = 0; q < c->model.n_prim; ++q) rb = std::fmax(rb, c->extras.prim_bound[q]);
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::fmin(lo[k], host[i].c[k] - host[i].bound);
+      hi[k] = std::fmax(hi[k], host[i].c[k] + host[i].bound);
+    }
+  constexpr int kProbe = 2048;
+  std::vector<double> probe(3 * kProbe), dist(kProbe);
+  uint64_t rng = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < 3 * kProbe; ++i) {
+    rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+    const double u = static_cast<double>(rng >> 11) * (1.0 / 9007199254740992.0);
+    probe[i] = lo[i % 3] + u * (hi[i % 3] - lo[i % 3]);
+  }
+  for (int i = 0; i < kProbe; ++i) {
+    double best2 = INFINITY;
+    for (size_t b = 0; b < n; ++b) {
+      const DevObs& o = host[b];
+      const double d[3] = {probe[3 * i] - o.c[0], probe[3 * i + 1] - o.c[1], probe[3 * i + 2] - o.c[2]};
+      double s2 = 0.0;
+      for (int a = 0; a < 3; ++a) {
+        const double t = std::fabs(o.R[a] * d[0] + o.R[3 + a] * d[1] + o.R[6 + a] * d[2]) - o.h[a];
+        if (t > 0.0) s2 += t * t;
+      }
+      best2 = std::fmin(best2, s2);
+    }
+    dist[i] = std::sqrt(best2);
+  }
+  std::sort(dist.begin(), dist.end());
+  double D = std::fmin(std::fmax(dist[(kProbe * 98) / 100], 0.05), 4.0);
+  GridHost gh;
+  bool built = false;
+  for (int attempt = 0; attempt < 3 && !built; ++attempt, D *= 0.5) {
+    if (build_grid(host.data(), n, rb + D, gh) != MVK_OK) continue;
+    built = true;
+    break;
+  }
+  if (!built) return MVK_OK;  // too dense for the grid's budget: the scan stays
+  double mean_len = 0.0;
+  for (int i = 0; i < kProbe; ++i) {
+    const uint16_t* ids;
+    mean_len += grid_query(gh, &probe[3 * i], &ids);
+  }
+  mean_len /= kProbe;
+  if (mean_len > 0.25 * static_cast<double>(n)) return MVK_OK;
+  if (int rc = c->dgrid_start.reserve(sizeof(uint32_t) * gh.start.size())) return rc;
+  if (int rc = c->dgrid_items.reserve(sizeof(uint16_t) * (gh.items.size() + kGridGroup))) return rc;
+  HIP_TRY(hipMemcpy(c->dgrid_start.p, gh.start.data(), sizeof(uint32_t) * gh.start.size(), hipMemcpyHostToDevice));
+  if (!gh.items.empty())
+    HIP_TRY(hipMemcpy(c->dgrid_items.p, gh.items.data(), sizeof(uint16_t) * gh.items.size(), hipMemcpyHostToDevice));
+  for (int k = 0; k < 3; ++k) { c->dgrid.origin[k] = gh.origin[k]; c->dgrid.n[k] = gh.n[k]; }
+  c->dgrid.inv_h = 1.0 / gh.h;
+  c->dgrid.pad = 0;
+  c->dgrid.start = static_cast<const uint32_t*>(c->dgrid_start.p);
+  c->dgrid.items = static_cast<const uint16_t*>(c->dgrid_items.p);
+  c->dgrid_radius = gh.radius;
+  return MVK_OK;
+}
+
 int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
   std::vector<DevObs> host;
   if (int rc = boxes_to_obs(boxes, n, host)) return rc;
@@ -306,7 +381,7 @@ int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
   c->n_obs = static_cast<int>(n);
   c->f32_range = range;
   c->f32_delta = static_cast<float>(4e-6 * range);
-  return MVK_OK;
+  return upload_distance_grid(c, host);
 }
 
 int check_params(const mvk_model* m, const mvk_params* p) {
@@ -339,6 +414,8 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
   a.obs = static_cast<const DevObs*>(c->obs.p);
   a.obsf = static_cast<const DevObsF*>(c->obsf.p);
   a.grid = c->grid;
+  a.dgrid = c->dgrid;
+  a.dgrid_radius = c->dgrid_radius;
   a.f32_delta = c->f32_delta;
   a.f32_range = c->f32_range;
   a.n_obs = c->n_obs;
@@ -528,7 +605,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   if (c->d_model) (void)hipFree(c->d_model);
   if (c->d_extras) (void)hipFree(c->d_extras);
-  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->queue, &c->queue_rec, &c->queue_counts, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
+  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start, &c->dgrid_items, &c->queue, &c->queue_rec, &c->queue_counts, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
                 &c->partial, &c->stats_out, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
   for (Buf* b : all) b->release();

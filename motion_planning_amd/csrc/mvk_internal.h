@@ -106,6 +106,8 @@ struct EvalArgs {
   const DevObs* obs;
   const DevObsF* obsf;   // n_obs + 1 entries: the last one is the padding id's never-hit box
   GridDev grid;
+  GridDev dgrid;        // full path: distance grid keyed by primitive centres (start == nullptr: scan all boxes)
+  double dgrid_radius;  // every box within this distance of a point is listed in the point's dgrid cell
   int32_t n_obs;
   float f32_delta;   // bound on the fp32 centre-distance error inside f32_range [m]
   double f32_range;  // coordinate magnitude up to which f32_delta holds

@@ -752,6 +752,30 @@ DEV double point_box_dist2(const double t[3], const double h[3]) {
   return fma(e0, e0, fma(e1, e1, e2 * e2));
 }
 
+// box primitive axes in the obstacle frame  Rr = O.R^T * PR
+DEV void box_rel(const DevObs& O, const double PR[9], double Rr[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      Rr[3 * r + c] = fma(O.R[r], PR[c], fma(O.R[3 + r], PR[3 + c], O.R[6 + r] * PR[6 + c]));
+}
+
+// exact separation of two disjoint boxes (A: centre t, axes Rr, half extents a, in the frame of B = [-b,b]^3):
+// the closest features always include a point on an edge of one of them
+DEV double box_box_exact(const double t[3], const double Rr[9], const double a[3], const double b[3]) {
+  double s2 = box_edges_to_box2(t, Rr, a, b);
+  double Rt[9], tb[3];  // B in A's frame
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Rt[3 * r + c] = Rr[3 * c + r];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) tb[r] = -fma(Rr[r], t[0], fma(Rr[3 + r], t[1], Rr[6 + r] * t[2]));
+  s2 = fmin(s2, box_edges_to_box2(tb, Rt, b, a));
+  return sqrt(s2);
+}
+
 // exact test of one primitive against one box (primitive kind is wave-uniform); t = primitive
 // centre in the box frame.  SIGNED: signed distance; otherwise only the sign is meaningful.
 // `cutoff` (SIGNED only): the caller keeps a running minimum; when the separating-axis bound of a box
@@ -773,29 +797,12 @@ DEV double narrow(int type, const double PR[9], double d0, double d1, double d2,
     if (SIGNED) d = sqrt(s2) - d0;
     else d = (s2 <= d0 * d0) ? 0.0 : 1.0;
   } else {
-    // box: primitive axes in the obstacle frame  Rr = O.R^T * PR
     double Rr[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        Rr[3 * r + c] = fma(O.R[r], PR[c], fma(O.R[3 + r], PR[3 + c], O.R[6 + r] * PR[6 + c]));
+    box_rel(O, PR, Rr);
     const double a[3] = {d0, d1, d2};
     if (SIGNED) {
       d = box_box_sat<true>(t, Rr, a, O.h);
-      if (d > 0.0 && d < cutoff) {
-        // exact separation: closest features always include a point on an edge
-        double s2 = box_edges_to_box2(t, Rr, a, O.h);
-        double Rt[9], tb[3];  // obstacle in the primitive's frame
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) Rt[3 * r + c] = Rr[3 * c + r];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) tb[r] = -fma(Rr[r], t[0], fma(Rr[3 + r], t[1], Rr[6 + r] * t[2]));
-        s2 = fmin(s2, box_edges_to_box2(tb, Rt, O.h, a));
-        d = sqrt(s2);
-      }
+      if (d > 0.0 && d < cutoff) d = box_box_exact(t, Rr, a, O.h);
     } else {
       d = box_box_sat<false>(t, Rr, a, O.h);
     }
@@ -1102,6 +1109,9 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
   for (int k = 0; k < 9; ++k) R[k] = Rw[k];
   p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
   double mind = INFINITY;
+  const bool use_grid = A.dgrid.start != nullptr;
+  const DevObsF* __restrict__ obsf = A.obsf;
+  const bool f32_safe = fmax(fabs(pos[0]), fmax(fabs(pos[1]), fabs(pos[2]))) + X->reach <= A.f32_range;
 #pragma unroll 1
   for (int k = 0; k < S::kSeg; ++k) {
     if (k > 0) advance_frame(M, sm, tid, k, R, p);
@@ -1115,47 +1125,119 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       const double rb = X->prim_bound[q];
       const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
 
-      // -- broadphase sweep: centre-to-box distance vs bounding radius -------
-      // obstacle boxes are read at wave-uniform addresses (scalar loads -> SGPRs)
-      auto centre_dist2 = [&](const DevObs& O) {
-        double t[3];
-        to_box_frame(O, pc, t);
-        return point_box_dist2(t, O.h);
-      };
+      // -- broadphase --------------------------------------------------------
+      const bool sphere = type == MVK_PRIM_SPHERE;
       int cnt = 0;
-      // pass 1: the primitive's origin lies inside it, so min_ob dist(origin, box)
-      // bounds this primitive's separation from above
-      double best2 = INFINITY;
+      bool scan = live;  // lanes whose candidates come from the sweep over all boxes
+      if (use_grid) {
+        // distance grid: the cell of the primitive's centre lists every box within dgrid_radius of it.
+        // fp32 pass 1 bounds this primitive's distance from above (its origin lies inside it); if every
+        // box that can undercut min(running minimum, that bound) is within dgrid_radius, the cell's
+        // list is complete and pass 2 takes the candidates from it.
+        unsigned gb, ge;
+        grid_cell(A.dgrid, pc, live && f32_safe, gb, ge);
+        const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
+        float best2f = INFINITY;
+#pragma unroll 1
+        for (unsigned g = gb; g < ge; ++g) {
+          const ushort4 v = *reinterpret_cast<const ushort4*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
+          const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < kGridGroup; ++e)
+            best2f = fminf(best2f, point_box_dist2_f32(obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]], x, y, z));
+        }
+        const double up = static_cast<double>(sqrtf(best2f)) * 1.000001 + static_cast<double>(A.f32_delta);
+        const double thr = rb + fmax(fmin(mind, up), 0.0);
+        if (live && f32_safe && thr + 2.0 * static_cast<double>(A.f32_delta) <= A.dgrid_radius) {
+          scan = false;
+          const float tf = (static_cast<float>(thr) + A.f32_delta) * 1.000001f;
+          const float thr2f = tf * tf;
+#pragma unroll 1
+          for (unsigned g = gb; g < ge; ++g) {
+            const ushort4 v = *reinterpret_cast<const ushort4*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
+            const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < kGridGroup; ++e) {
+              const float l2 = point_box_dist2_f32(obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]], x, y, z);
+              if (ids[e] != kGridNone && l2 <= thr2f) {
+                if (cnt < kListCap) sm.list[cnt * kBlock + tid] = ids[e];
+                ++cnt;
+              }
+            }
+          }
+        }
+      }
+      const bool swept = __any(scan);
+      if (swept) {
+        // sweep over all boxes: centre-to-box distance vs bounding radius; obstacle boxes are read at
+        // wave-uniform addresses (scalar loads -> SGPRs)
+        auto centre_dist2 = [&](const DevObs& O) {
+          double t[3];
+          to_box_frame(O, pc, t);
+          return point_box_dist2(t, O.h);
+        };
+        // pass 1: the primitive's origin lies inside it, so min_ob dist(origin, box)
+        // bounds this primitive's separation from above
+        double best2 = INFINITY;
 #pragma unroll 2
-      for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
-      if (type == MVK_PRIM_SPHERE) {
-        mind = fmin(mind, sqrt(best2) - d0);  // exact for a sphere
-      } else {
-        // pass 2: keep pairs whose lower bound (centre distance - bounding radius)
-        // can still undercut the running minimum, and every possibly-touching pair
-        const double thr = rb + fmax(fmin(mind, sqrt(best2)), 0.0);
-        const double thr2 = thr * thr;
+        for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
+        if (sphere) {
+          mind = fmin(mind, sqrt(best2) - d0);  // exact for a sphere
+        } else {
+          // pass 2: keep pairs whose lower bound (centre distance - bounding radius)
+          // can still undercut the running minimum, and every possibly-touching pair
+          const double thr = rb + fmax(fmin(mind, sqrt(best2)), 0.0);
+          const double thr2 = thr * thr;
 #pragma unroll 2
-        for (int ob = 0; ob < A.n_obs; ++ob) {
-          if (live && centre_dist2(obs[ob]) <= thr2) {
-            if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
-            ++cnt;
+          for (int ob = 0; ob < A.n_obs; ++ob) {
+            if (scan && centre_dist2(obs[ob]) <= thr2) {
+              if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
+              ++cnt;
+            }
           }
         }
       }
       // -- narrowphase drain: kind is wave-uniform, list length is per lane ---
       const bool overflow = cnt > kListCap;
       int todo = live ? (overflow ? A.n_obs : cnt) : 0;
-      if (type == MVK_PRIM_SPHERE) todo = 0;
+      if (sphere && swept) todo = 0;
+      if (type == MVK_PRIM_BOX) {
+        // The exact box-box separation (24 edge-to-box distances) costs ~30x the separating-axis bound, and
+        // only the few candidates whose bound undercuts the running minimum need it.  Lanes therefore scan
+        // their lists with the bound alone, each stopping at its next candidate that does need the exact
+        // distance, and the wave then runs the exact code once for all of them: the wave executes it
+        // max-over-lanes(exact calls) times instead of max-over-lanes(list length) times.
+        const double a[3] = {d0, d1, d2};
+        int e = 0;
 #pragma unroll 1
-      for (int e = 0; __any(e < todo); ++e) {
-        if (e < todo) {
-          // on overflow fall back to testing every obstacle for this primitive
-          const int ob = overflow ? e : sm.list[e * kBlock + tid];
-          const DevObs O = obs[ob];
-          double t[3];
-          to_box_frame(O, pc, t);
-          mind = fmin(mind, narrow<true>(type, PR, d0, d1, d2, O, t, mind));
+        while (__any(e < todo)) {
+          bool need = false;
+          double Rr[9], t[3], h[3];
+#pragma unroll 1
+          while (e < todo && !need) {
+            // on overflow fall back to testing every obstacle for this primitive
+            const int ob = overflow ? e : sm.list[e * kBlock + tid];
+            const DevObs& O = obs[ob];
+            to_box_frame(O, pc, t);
+            box_rel(O, PR, Rr);
+            h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
+            const double g = box_box_sat<true>(t, Rr, a, h);
+            if (g <= 0.0) mind = fmin(mind, g);
+            else need = g < mind;
+            ++e;
+          }
+          if (need) mind = fmin(mind, box_box_exact(t, Rr, a, h));
+        }
+      } else {
+#pragma unroll 1
+        for (int e = 0; __any(e < todo); ++e) {
+          if (e < todo) {
+            const int ob = overflow ? e : sm.list[e * kBlock + tid];
+            const DevObs O = obs[ob];
+            double t[3];
+            to_box_frame(O, pc, t);
+            mind = fmin(mind, sphere ? sqrt(point_box_dist2(t, O.h)) - d0 : narrow<true>(type, PR, d0, d1, d2, O, t, mind));
+          }
         }
       }
     }
