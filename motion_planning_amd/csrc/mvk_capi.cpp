@@ -98,7 +98,7 @@ struct mvk_ctx {
   DevExtras extras{};
   mvk_model* d_model = nullptr;
   DevExtras* d_extras = nullptr;
-  Buf obs, obsf, grid_start, grid_items, dgrid_start, dgrid_items;
+  Buf obs, obsf, grid_start, grid_items, dgrid_start[2], dgrid_items[2];
   // flag path hand-off between the screen and the exact stage (see EvalArgs).  Two alternating sets
   // of queue counters: call k appends to set k%2 and zeroes set (k+1)%2, so no memset sits between
   // launches.  Calls on one ctx must therefore be ordered with respect to each other (one stream at a time).
@@ -113,8 +113,8 @@ struct mvk_ctx {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool profiling = false, timed = false;
   GridDev grid{};
-  GridDev dgrid{};  // distance grid of the full path (start == nullptr: not in use for this scene)
-  double dgrid_radius = 0.0;
+  GridDev dgrid[2] = {};  // distance grids: [0] full path, [1] avoidance rows (start == nullptr: not in use for this scene)
+  double dgrid_radius[2] = {0.0, 0.0};
   int n_obs = 0;
   float f32_delta = 0.0f;
   double f32_range = 0.0;
@@ -264,18 +264,25 @@ int boxes_to_obs(const mvk_box* boxes, size_t n, std::vector<DevObs>& host) {
   return MVK_OK;
 }
 
-// Distance grid of the full path (minimum distances).  A primitive whose centre lies in a cell sees in
-// that cell's list every box within dgrid_radius = (largest primitive bounding radius + D) of the centre,
-// so whenever an upper bound U <= D of the state's distance is known, the cell list holds every box that
-// can realise the minimum for that primitive and the scan over all boxes is not needed.  D is read off
-// the scene: the 98th percentile of the distance from a point of the obstacles' bounding volume to the
-// nearest box (points farther than that fall back to the scan over all boxes).  Scenes where the lists
-// would not be much shorter than the whole set keep the scan (scalar loads at wave-uniform addresses).
-int upload_distance_grid(mvk_ctx* c, const std::vector<DevObs>& host) {
-  c->dgrid = GridDev{};
-  c->dgrid_radius = 0.0;
+// Distance grids of the distance kernels (full path: minimum distance per state; avoidance rows: nearest box per
+// primitive).  A primitive whose centre lies in a cell sees in that cell's list every box within
+// radius = (largest primitive bounding radius + slack) of the centre, so whenever an upper bound <= slack of
+// the distance sought is known, the list holds every box that can realise the minimum and the sweep over all
+// boxes is not needed.  The slack is read off the scene: a percentile of the distance from a point of the
+// obstacles' bounding volume to the nearest box.  The full path bounds a state by its closest primitive and
+// takes the 70th percentile (short lists; a state needs the sweep only when the whole robot is farther than
+// that from every box); the avoidance rows need the nearest box of every primitive on its own and take the
+// 95th.  Measured on c2 / c2k / c3 / c5 (profiles/full_time.py with MVK_DISTANCE_GRID_PCT).  Scenes where the
+// lists would not be much shorter than the whole set keep the sweep (scalar loads at wave-uniform addresses).
+int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
+  for (int g = 0; g < 2; ++g) {
+    c->dgrid[g] = GridDev{};
+    c->dgrid_radius[g] = 0.0;
+  }
   const size_t n = host.size();
-  if (n < 128) return MVK_OK;
+  if (n < 64) return MVK_OK;
+  // diagnostics (profiles/full_time.py, tests): keep the sweep over all boxes for scenes set from now on
+  if (const char* off = std::getenv("MVK_NO_DISTANCE_GRID")) if (off[0] == '1') return MVK_OK;
   double rb = 0.0;
   for (int q = 0; q < c->model.n_prim; ++q) rb = std::fmax(rb, c->extras.prim_bound[q]);
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -307,33 +314,37 @@ int upload_distance_grid(mvk_ctx* c, const std::vector<DevObs>& host) {
     dist[i] = std::sqrt(best2);
   }
   std::sort(dist.begin(), dist.end());
-  double D = std::fmin(std::fmax(dist[(kProbe * 98) / 100], 0.05), 4.0);
-  GridHost gh;
-  bool built = false;
-  for (int attempt = 0; attempt < 3 && !built; ++attempt, D *= 0.5) {
-    if (build_grid(host.data(), n, rb + D, gh) != MVK_OK) continue;
-    built = true;
-    break;
+  for (int g = 0; g < 2; ++g) {
+    int pct = g == 0 ? 70 : 95;
+    if (const char* ov = std::getenv("MVK_DISTANCE_GRID_PCT")) if (std::atoi(ov) > 0 && std::atoi(ov) < 100) pct = std::atoi(ov);  // diagnostics
+    double slack = std::fmin(std::fmax(dist[(kProbe * pct) / 100], 0.05), 4.0);
+    GridHost gh;
+    bool built = false;
+    for (int attempt = 0; attempt < 3 && !built; ++attempt, slack *= 0.5) built = build_grid(host.data(), n, rb + slack, gh) == MVK_OK;
+    if (!built) continue;  // too dense for the grid's budget: the sweep stays
+    double mean_len = 0.0;
+    for (int i = 0; i < kProbe; ++i) {
+      const uint16_t* ids;
+      mean_len += grid_query(gh, &probe[3 * i], &ids);
+    }
+    mean_len /= kProbe;
+    if (mean_len > 0.25 * static_cast<double>(n)) continue;
+    if (int rc = c->dgrid_start[g].reserve(sizeof(uint32_t) * gh.start.size())) return rc;
+    if (int rc = c->dgrid_items[g].reserve(sizeof(uint16_t) * (gh.items.size() + kGridGroup))) return rc;
+    HIP_TRY(hipMemcpy(c->dgrid_start[g].p, gh.start.data(), sizeof(uint32_t) * gh.start.size(), hipMemcpyHostToDevice));
+    if (!gh.items.empty())
+      HIP_TRY(hipMemcpy(c->dgrid_items[g].p, gh.items.data(), sizeof(uint16_t) * gh.items.size(), hipMemcpyHostToDevice));
+    GridDev& d = c->dgrid[g];
+    for (int k = 0; k < 3; ++k) { d.origin[k] = gh.origin[k]; d.n[k] = gh.n[k]; }
+    d.inv_h = 1.0 / gh.h;
+    d.pad = 0;
+    d.start = static_cast<const uint32_t*>(c->dgrid_start[g].p);
+    d.items = static_cast<const uint16_t*>(c->dgrid_items[g].p);
+    c->dgrid_radius[g] = gh.radius;
+    if (std::getenv("MVK_DISTANCE_GRID_TRACE"))
+      std::fprintf(stderr, "mvk: distance grid %d: radius %.3f (slack %.3f), cell %.3f, %d x %d x %d cells, mean list %.1f of %zu boxes\n",
+                   g, gh.radius, gh.radius - rb, gh.h, gh.n[0], gh.n[1], gh.n[2], mean_len, n);
   }
-  if (!built) return MVK_OK;  // too dense for the grid's budget: the scan stays
-  double mean_len = 0.0;
-  for (int i = 0; i < kProbe; ++i) {
-    const uint16_t* ids;
-    mean_len += grid_query(gh, &probe[3 * i], &ids);
-  }
-  mean_len /= kProbe;
-  if (mean_len > 0.25 * static_cast<double>(n)) return MVK_OK;
-  if (int rc = c->dgrid_start.reserve(sizeof(uint32_t) * gh.start.size())) return rc;
-  if (int rc = c->dgrid_items.reserve(sizeof(uint16_t) * (gh.items.size() + kGridGroup))) return rc;
-  HIP_TRY(hipMemcpy(c->dgrid_start.p, gh.start.data(), sizeof(uint32_t) * gh.start.size(), hipMemcpyHostToDevice));
-  if (!gh.items.empty())
-    HIP_TRY(hipMemcpy(c->dgrid_items.p, gh.items.data(), sizeof(uint16_t) * gh.items.size(), hipMemcpyHostToDevice));
-  for (int k = 0; k < 3; ++k) { c->dgrid.origin[k] = gh.origin[k]; c->dgrid.n[k] = gh.n[k]; }
-  c->dgrid.inv_h = 1.0 / gh.h;
-  c->dgrid.pad = 0;
-  c->dgrid.start = static_cast<const uint32_t*>(c->dgrid_start.p);
-  c->dgrid.items = static_cast<const uint16_t*>(c->dgrid_items.p);
-  c->dgrid_radius = gh.radius;
   return MVK_OK;
 }
 
@@ -381,7 +392,7 @@ int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
   c->n_obs = static_cast<int>(n);
   c->f32_range = range;
   c->f32_delta = static_cast<float>(4e-6 * range);
-  return upload_distance_grid(c, host);
+  return upload_distance_grids(c, host);
 }
 
 int check_params(const mvk_model* m, const mvk_params* p) {
@@ -414,8 +425,8 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
   a.obs = static_cast<const DevObs*>(c->obs.p);
   a.obsf = static_cast<const DevObsF*>(c->obsf.p);
   a.grid = c->grid;
-  a.dgrid = c->dgrid;
-  a.dgrid_radius = c->dgrid_radius;
+  a.dgrid = c->dgrid[0];
+  a.dgrid_radius = c->dgrid_radius[0];
   a.f32_delta = c->f32_delta;
   a.f32_range = c->f32_range;
   a.n_obs = c->n_obs;
@@ -605,7 +616,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   if (c->d_model) (void)hipFree(c->d_model);
   if (c->d_extras) (void)hipFree(c->d_extras);
-  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start, &c->dgrid_items, &c->queue, &c->queue_rec, &c->queue_counts, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
+  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start[0], &c->dgrid_items[0], &c->dgrid_start[1], &c->dgrid_items[1], &c->queue, &c->queue_rec, &c->queue_counts, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
                 &c->partial, &c->stats_out, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
   for (Buf* b : all) b->release();
@@ -877,6 +888,8 @@ extern "C" int mvk_collision_avoidance_batch_dev(mvk_ctx* c, const double* d_soa
   a.n = n;
   a.ld = ld;
   a.layout = layout;
+  a.dgrid = c->dgrid[1];
+  a.dgrid_radius = c->dgrid_radius[1];
   a.av_gain = prm->damping_gain;
   a.av_range = prm->constraint_range;
   a.av_forbid = prm->forbidden_range;

@@ -43,8 +43,10 @@ __device__ unsigned long long g_prof[48];
 #ifdef MVK_PROF
 #define PROF_LANES(idx, pred) do { const unsigned long long b__ = __ballot(pred); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_prof[idx], (unsigned long long)__popcll(b__)); } while (0)
 #define PROF_WAVE(idx) do { if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_prof[idx], 1ull); } while (0)
+#define PROF_SUM(idx, val) do { unsigned long long v__ = (unsigned long long)(val); for (int o__ = 32; o__; o__ >>= 1) v__ += __shfl_xor(v__, o__); if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[idx], v__); } while (0)
 #else
 #define PROF_LANES(idx, pred) do { } while (0)
+#define PROF_SUM(idx, val) do { } while (0)
 #define PROF_WAVE(idx) do { } while (0)
 #endif
 #ifdef MVK_PROFT
@@ -1096,6 +1098,161 @@ DEV bool exact_pair(const mvk_model* __restrict__ M, const DevExtras* __restrict
 }
 
 // ------------------------------------------------------------------------
+// candidate boxes of one primitive for the distance kernels (full_kernel, avoid_kernel)
+// ------------------------------------------------------------------------
+// Distance grid (mvk_capi.cpp, upload_distance_grid): the cell of a primitive's centre lists every box within
+// A.dgrid_radius of it.
+// grid_upper_bound: fp32 minimum of the centre's distance over the cell's list, padded by the fp32 error bound:
+// an upper bound of the primitive's distance (its origin lies inside it); +inf for an empty list.
+DEV double grid_upper_bound(const EvalArgs& A, bool on, const double pc[3]) {
+  const DevObsF* __restrict__ obsf = A.obsf;
+  unsigned gb, ge;
+  grid_cell(A.dgrid, pc, on, gb, ge);
+  const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
+  float best2f = INFINITY;
+#pragma unroll 1
+  for (unsigned g = gb; g < ge; ++g) {
+    const ushort4 v = *reinterpret_cast<const ushort4*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
+    const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < kGridGroup; ++e)
+      best2f = fminf(best2f, point_box_dist2_f32(obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]], x, y, z));
+  }
+  return static_cast<double>(sqrtf(best2f)) * 1.000001 + static_cast<double>(A.f32_delta);
+}
+
+// grid_collect: `bound` is an upper bound of the distance sought.  Only boxes whose centre distance is at most
+// thr = rb + max(bound, 0) can undercut it (lower bound: centre distance - bounding radius); when thr is within
+// the grid's radius the cell's list holds all of them: they join the lane's candidate list, in ascending box
+// order, and the function returns true.  Otherwise (far from every box, outside the grid volume, beyond the
+// fp32 range: `on` false) nothing is listed.
+DEV bool grid_collect(const EvalArgs& A, const Smem& sm, bool on, const double pc[3], double rb, double bound, int& cnt) {
+  const int tid = threadIdx.x;
+  const DevObsF* __restrict__ obsf = A.obsf;
+  const double thr = rb + fmax(bound, 0.0);
+  if (!(on && thr + 2.0 * static_cast<double>(A.f32_delta) <= A.dgrid_radius)) return false;
+  unsigned gb, ge;
+  grid_cell(A.dgrid, pc, on, gb, ge);
+  const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
+  const float tf = (static_cast<float>(thr) + A.f32_delta) * 1.000001f;
+  const float thr2f = tf * tf;
+#pragma unroll 1
+  for (unsigned g = gb; g < ge; ++g) {
+    const ushort4 v = *reinterpret_cast<const ushort4*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
+    const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < kGridGroup; ++e) {
+      const float l2 = point_box_dist2_f32(obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]], x, y, z);
+      if (ids[e] != kGridNone && l2 <= thr2f) {
+        if (cnt < kListCap) sm.list[cnt * kBlock + tid] = ids[e];
+        ++cnt;
+      }
+    }
+  }
+  return true;
+}
+
+// The sweep over all boxes for the lanes the grid could not answer (`scan`; typically primitives that stick out
+// of the obstacles' volume), in fp32 and by the whole wave: every lane holds one box per round and tests it for
+// each such lane in turn (centre broadcast from that lane), so a box is loaded once per round however many lanes
+// are served, and no load waits on another.  Pass 1: wave minimum of the centre distances -> upper bound of the
+// lane's distance; pass 2: the boxes that can undercut min(bound, that) join the lane's candidate list, in
+// ascending box order.  The fp32 error bound pads both, as in grid_candidates.
+DEV float bcast_lane(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+
+DEV void sweep_for_lanes_f32(const EvalArgs& A, const Smem& sm, bool scan, const double pc[3], double rb, double bound, int& cnt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave_tid = tid - lane;
+  const unsigned long long todo = __ballot(scan);
+  if (todo == 0ull) return;
+  const DevObsF* __restrict__ obsf = A.obsf;
+  const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
+  float up2 = INFINITY;
+#pragma unroll 1
+  for (int b = 0; b < A.n_obs; b += 64) {
+    const DevObsF F = obsf[b + lane < A.n_obs ? b + lane : A.n_obs];  // past the end: the padding id's far box
+#pragma unroll 1
+    for (unsigned long long m = todo; m; m &= m - 1ull) {
+      const int src = __ffsll(static_cast<long long>(m)) - 1;
+      float d2 = point_box_dist2_f32(F, bcast_lane(x, src), bcast_lane(y, src), bcast_lane(z, src));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) d2 = fminf(d2, __shfl_xor(d2, o));
+      if (lane == src) up2 = fminf(up2, d2);
+    }
+  }
+  const double up = static_cast<double>(sqrtf(up2)) * 1.000001 + static_cast<double>(A.f32_delta);
+  const double thr = rb + fmax(fmin(bound, up), 0.0);
+  const float tf = (static_cast<float>(thr) + A.f32_delta) * 1.000001f;
+  const float thr2f = tf * tf;
+  int n = 0;
+#pragma unroll 1
+  for (int b = 0; b < A.n_obs; b += 64) {
+    const bool real = b + lane < A.n_obs;
+    const DevObsF F = obsf[real ? b + lane : A.n_obs];
+#pragma unroll 1
+    for (unsigned long long m = todo; m; m &= m - 1ull) {
+      const int src = __ffsll(static_cast<long long>(m)) - 1;
+      const float d2 = point_box_dist2_f32(F, bcast_lane(x, src), bcast_lane(y, src), bcast_lane(z, src));
+      const bool pass = real && d2 <= bcast_lane(thr2f, src);
+      const unsigned long long pm = __ballot(pass);
+      const int at = __builtin_amdgcn_readlane(n, src);
+      if (pass) {
+        const int slot = at + __popcll(pm & ((1ull << lane) - 1ull));
+        if (slot < kListCap) sm.list[slot * kBlock + wave_tid + src] = static_cast<unsigned short>(b + lane);
+      }
+      if (lane == src) n += __popcll(pm);
+    }
+  }
+  if (scan) cnt = n;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The same sweep in fp64 for lanes beyond the coordinate range the fp32 bounds are trusted for, one such lane at a time: lane i takes boxes i, i + 64, ...; a wave minimum gives the centre's distance to the
+// nearest box (best2, exact fp64), and the boxes that can still undercut min(bound, that distance) are
+// appended to the source lane's candidate list in ascending order.  ~2 * n_obs / 64 rounds per lane served
+// instead of 2 * n_obs for the whole wave.
+DEV void sweep_for_lanes(const EvalArgs& A, const DevObs* __restrict__ obs, const Smem& sm, bool scan, const double pc[3],
+                         double rb, double bound, double& best2, int& cnt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave_tid = tid - lane;
+  unsigned long long todo = __ballot(scan);
+  if (todo == 0ull) return;
+  auto centre_dist2 = [&](int ob, const double c[3]) {
+    double t[3];
+    to_box_frame(obs[ob], c, t);
+    return point_box_dist2(t, obs[ob].h);
+  };
+#pragma unroll 1
+  while (todo) {
+    const int src = __ffsll(static_cast<long long>(todo)) - 1;
+    todo &= todo - 1ull;
+    const double c[3] = {__shfl(pc[0], src), __shfl(pc[1], src), __shfl(pc[2], src)};
+    const double bnd = __shfl(bound, src);
+    double b2 = INFINITY;
+#pragma unroll 1
+    for (int ob = lane; ob < A.n_obs; ob += 64) b2 = fmin(b2, centre_dist2(ob, c));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b2 = fmin(b2, __shfl_xor(b2, o));
+    const double thr = rb + fmax(fmin(bnd, sqrt(b2)), 0.0);
+    const double thr2 = thr * thr * (1.0 + 1e-12);
+    int n = 0;
+#pragma unroll 1
+    for (int b = 0; b < A.n_obs; b += 64) {
+      const int ob = b + lane;
+      const bool pass = ob < A.n_obs && centre_dist2(ob, c) <= thr2;
+      const unsigned long long pm = __ballot(pass);
+      if (pass) {
+        const int slot = n + __popcll(pm & ((1ull << lane) - 1ull));
+        if (slot < kListCap) sm.list[slot * kBlock + wave_tid + src] = static_cast<unsigned short>(ob);
+      }
+      n += __popcll(pm);
+    }
+    if (lane == src) { best2 = b2; cnt = n; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------
 // full path: exact minimum distance over every (primitive, box) pair
 // ------------------------------------------------------------------------
 template <int ROBOT, int NL>
@@ -1110,8 +1267,28 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
   p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
   double mind = INFINITY;
   const bool use_grid = A.dgrid.start != nullptr;
-  const DevObsF* __restrict__ obsf = A.obsf;
   const bool f32_safe = fmax(fabs(pos[0]), fmax(fabs(pos[1]), fabs(pos[2]))) + X->reach <= A.f32_range;
+  // with the distance grid, a first walk over the chain bounds the state's distance from above: the smallest
+  // centre-to-listed-box distance over all primitives.  The second walk then collects, per primitive, only the
+  // boxes that can undercut that bound, and a lane needs the sweep over all boxes only when the whole robot
+  // is farther from every box than the grid's slack.
+  double upper = INFINITY;
+  if (use_grid) {
+#pragma unroll 1
+    for (int k = 0; k < S::kSeg; ++k) {
+      if (k > 0) advance_frame(M, sm, tid, k, R, p);
+      const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
+#pragma unroll 1
+      for (int qi = pb; qi < pe; ++qi) {
+        double pc[3];
+        prim_pose<S::kGimbal, false>(M, X->prim_order[qi], R, p, pc, nullptr);
+        upper = fmin(upper, grid_upper_bound(A, live && f32_safe, pc));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = Rw[k];
+    p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
+  }
 #pragma unroll 1
   for (int k = 0; k < S::kSeg; ++k) {
     if (k > 0) advance_frame(M, sm, tid, k, R, p);
@@ -1129,46 +1306,21 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       const bool sphere = type == MVK_PRIM_SPHERE;
       int cnt = 0;
       bool scan = live;  // lanes whose candidates come from the sweep over all boxes
+      bool swept = false;
       if (use_grid) {
-        // distance grid: the cell of the primitive's centre lists every box within dgrid_radius of it.
-        // fp32 pass 1 bounds this primitive's distance from above (its origin lies inside it); if every
-        // box that can undercut min(running minimum, that bound) is within dgrid_radius, the cell's
-        // list is complete and pass 2 takes the candidates from it.
-        unsigned gb, ge;
-        grid_cell(A.dgrid, pc, live && f32_safe, gb, ge);
-        const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
-        float best2f = INFINITY;
-#pragma unroll 1
-        for (unsigned g = gb; g < ge; ++g) {
-          const ushort4 v = *reinterpret_cast<const ushort4*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
-          const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int e = 0; e < kGridGroup; ++e)
-            best2f = fminf(best2f, point_box_dist2_f32(obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]], x, y, z));
+        const double bound = fmin(mind, upper);
+        if (grid_collect(A, sm, live && f32_safe, pc, rb, bound, cnt)) scan = false;
+        sweep_for_lanes_f32(A, sm, scan && f32_safe, pc, rb, bound, cnt);
+        const bool slow = scan && !f32_safe;
+        double b2 = INFINITY;
+        int c2 = 0;
+        sweep_for_lanes(A, obs, sm, slow, pc, rb, mind, b2, c2);
+        if (slow) {
+          if (sphere) mind = fmin(mind, sqrt(b2) - d0);  // exact for a sphere
+          else cnt = c2;
         }
-        const double up = static_cast<double>(sqrtf(best2f)) * 1.000001 + static_cast<double>(A.f32_delta);
-        const double thr = rb + fmax(fmin(mind, up), 0.0);
-        if (live && f32_safe && thr + 2.0 * static_cast<double>(A.f32_delta) <= A.dgrid_radius) {
-          scan = false;
-          const float tf = (static_cast<float>(thr) + A.f32_delta) * 1.000001f;
-          const float thr2f = tf * tf;
-#pragma unroll 1
-          for (unsigned g = gb; g < ge; ++g) {
-            const ushort4 v = *reinterpret_cast<const ushort4*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
-            const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < kGridGroup; ++e) {
-              const float l2 = point_box_dist2_f32(obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]], x, y, z);
-              if (ids[e] != kGridNone && l2 <= thr2f) {
-                if (cnt < kListCap) sm.list[cnt * kBlock + tid] = ids[e];
-                ++cnt;
-              }
-            }
-          }
-        }
-      }
-      const bool swept = __any(scan);
-      if (swept) {
+      } else if (__any(scan)) {
+        swept = true;
         // sweep over all boxes: centre-to-box distance vs bounding radius; obstacle boxes are read at
         // wave-uniform addresses (scalar loads -> SGPRs)
         auto centre_dist2 = [&](const DevObs& O) {
@@ -1201,6 +1353,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       const bool overflow = cnt > kListCap;
       int todo = live ? (overflow ? A.n_obs : cnt) : 0;
       if (sphere && swept) todo = 0;
+      PROF_LANES(30, live); PROF_LANES(31, live && scan); PROF_LANES(32, live && overflow); PROF_SUM(33, live ? cnt : 0);
       if (type == MVK_PRIM_BOX) {
         // The exact box-box separation (24 edge-to-box distances) costs ~30x the separating-axis bound, and
         // only the few candidates whose bound undercuts the running minimum need it.  Lanes therefore scan
@@ -1932,6 +2085,8 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   for (int k = 0; k < 9; ++k) R[k] = Rw[k];
   p[0] = st[0]; p[1] = st[1]; p[2] = st[2];
   bool ok = true;
+  const bool use_grid = A.dgrid.start != nullptr;
+  const bool f32_safe = fmax(fabs(st[0]), fmax(fabs(st[1]), fabs(st[2]))) + X->reach <= A.f32_range;
 #pragma unroll 1
   for (int k = 0; k < S::kSeg; ++k) {
     if (k > 0) advance_frame(M, sm, tid, k, R, p);
@@ -1944,27 +2099,40 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
       const double rb = X->prim_bound[q];
       const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
-      auto centre_dist2 = [&](const DevObs& O) {
-        double t[3];
-        to_box_frame(O, pc, t);
-        return point_box_dist2(t, O.h);
-      };
-      // the primitive's origin lies inside it: the nearest box to the origin bounds the separation from above
-      double best2 = INFINITY;
-#pragma unroll 2
-      for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
-      const double thr = rb + sqrt(best2);
-      const double thr2 = thr * thr * (1.0 + 1e-12);
       int cnt = 0;
+      if (use_grid) {
+        bool scan = in_range;
+        if (grid_collect(A, sm, in_range && f32_safe, pc, rb, grid_upper_bound(A, in_range && f32_safe, pc), cnt)) scan = false;
+        double b2 = INFINITY;
+        int c2 = 0;
+        sweep_for_lanes_f32(A, sm, scan && f32_safe, pc, rb, INFINITY, cnt);
+        const bool slow = scan && !f32_safe;
+        sweep_for_lanes(A, obs, sm, slow, pc, rb, INFINITY, b2, c2);
+        PROF_LANES(37, scan);
+        if (slow) cnt = c2;
+      } else {
+        auto centre_dist2 = [&](const DevObs& O) {
+          double t[3];
+          to_box_frame(O, pc, t);
+          return point_box_dist2(t, O.h);
+        };
+        // the primitive's origin lies inside it: the nearest box to the origin bounds the separation from above
+        double best2 = INFINITY;
 #pragma unroll 2
-      for (int ob = 0; ob < A.n_obs; ++ob) {
-        if (centre_dist2(obs[ob]) <= thr2) {
-          if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
-          ++cnt;
+        for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
+        const double thr = rb + sqrt(best2);
+        const double thr2 = thr * thr * (1.0 + 1e-12);
+#pragma unroll 2
+        for (int ob = 0; ob < A.n_obs; ++ob) {
+          if (centre_dist2(obs[ob]) <= thr2) {
+            if (cnt < kListCap) sm.list[cnt * kBlock + tid] = static_cast<unsigned short>(ob);
+            ++cnt;
+          }
         }
       }
       const bool overflow = cnt > kListCap;
-      const int todo = overflow ? A.n_obs : cnt;
+      const int todo = (use_grid && !in_range) ? 0 : (overflow ? A.n_obs : cnt);
+      PROF_LANES(36, in_range); PROF_LANES(38, in_range && overflow); PROF_SUM(39, in_range ? cnt : 0);
       double best = INFINITY, br[3] = {NAN, NAN, NAN}, be[3] = {NAN, NAN, NAN};
       int bi = -1;
 #pragma unroll 1

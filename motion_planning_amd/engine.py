@@ -296,6 +296,19 @@ class Engine:
                                                          self._dp(d_min_dist), self._dp(d_margin), self._dp(d_band),
                                                          self._stream(stream)))
 
+    def collision_avoidance_batch_dev(self, d_soa, layout, d_out, damping_gain=0.01, constraint_range=0.03,
+                                      forbidden_range=0.01, full_body=True, stream=None):
+        """device-pointer form of collision_avoidance_batch: d_out maps any of dist [P, ld], box (int32) [P, ld],
+        p_env / p_robot [3P, ld], row [(6+J)P, ld], lb [P, ld], ok (uint8) [ld] to device tensors whose row pitch
+        is that of d_soa; outputs left out are not written"""
+        rows, n = d_soa.shape
+        ld = d_soa.stride(0)
+        assert d_soa.stride(1) == 1 and rows == self.state_dim(layout)
+        prm = A.AvoidParams(damping_gain, constraint_range, forbidden_range, int(full_body))
+        o = A.AvoidOut(*[self._dp(d_out.get(k)) for k in ("dist", "box", "p_env", "p_robot", "row", "lb", "ok")])
+        _check(self.lib, self.lib.mvk_collision_avoidance_batch_dev(self.ctx, self._dp(d_soa), n, ld, layout, C.byref(prm),
+                                                                    C.byref(o), self._stream(stream)))
+
     def is_valid_mask_dev(self, d_soa, layout, d_mask, stream=None):
         rows, n = d_soa.shape
         ld = d_soa.stride(0)

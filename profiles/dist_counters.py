@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""event counters of the distance kernels (library built with -DMVK_PROF, MVK_LIB=<it>): per (state, primitive),
+how many lanes the distance grid could not answer, how many candidate lists overflowed, mean list length"""
+import ctypes as C
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import common
+import motion_planning_amd as mp
+lib = mp.abi.load()
+n = 1 << 18
+for name in sys.argv[1:] or ["c2k", "c3", "c5"]:
+    w = {"c2": common.config2, "c2k": common.config2k, "c3": common.config3, "c5": common.config5}[name](n=n)
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    d = torch.from_numpy(w.soa).cuda()
+    md = torch.zeros(n, dtype=torch.float64, device="cuda")
+    fl = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    buf = (C.c_ulonglong * 48)()
+    lib.mvk_debug_prof(None, 1)
+    eng.is_valid_batch_dev(d, w.layout, d_flags=fl, d_min_dist=md)
+    torch.cuda.synchronize()
+    lib.mvk_debug_prof(buf, 1)
+    b = [int(x) for x in buf]
+    print(f"{name} full : lane-prims {b[30]}, swept {b[31]} ({b[31] / max(b[30], 1):.4f}), overflow {b[32]} ({b[32] / max(b[30], 1):.4f}), mean candidates {b[33] / max(b[30], 1):.2f}")
+    P = w.model.n_prim
+    outs = dict(dist=torch.zeros(P, n, dtype=torch.float64, device="cuda"), ok=torch.zeros(n, dtype=torch.uint8, device="cuda"))
+    eng.collision_avoidance_batch_dev(d, w.layout, outs)
+    torch.cuda.synchronize()
+    lib.mvk_debug_prof(buf, 1)
+    b = [int(x) for x in buf]
+    print(f"{name} avoid: lane-prims {b[36]}, swept {b[37]} ({b[37] / max(b[36], 1):.4f}), overflow {b[38]} ({b[38] / max(b[36], 1):.4f}), mean candidates {b[39] / max(b[36], 1):.2f}", flush=True)
+    eng.close()

@@ -16,16 +16,21 @@ from motion_planning_amd import _abi as A
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind,n_links,orient", [("hydrus", 4, "so3"), ("hydrus", 6, "yaw"), ("hydrus", 8, "so3"), ("dragon", 4, "so3")])
-def test_avoidance_rows_match_the_oracle(kind, n_links, orient):
+# the 600-box worlds are dense enough for the distance grid (candidates from the cell of each primitive's centre,
+# wave-cooperative sweep for the lanes it cannot answer); the 40-box worlds take the sweep over all boxes
+@pytest.mark.parametrize("kind,n_links,orient,n_boxes", [("hydrus", 4, "so3", 40), ("hydrus", 6, "yaw", 40), ("hydrus", 8, "so3", 40),
+                                                         ("dragon", 4, "so3", 40), ("hydrus", 6, "so3", 600), ("dragon", 4, "so3", 600)])
+def test_avoidance_rows_match_the_oracle(kind, n_links, orient, n_boxes):
     rng = np.random.default_rng(11)
     model = mp.make_model(kind, n_links)
     params = mp.default_params(model, A.MODE_JOINTS_AND_BASE, A.SE3)
     J, P, W = model.n_joint, model.n_prim, 6 + model.n_joint
-    boxes = common.random_boxes(rng, 40, [-3, -3, -2], [3, 3, 2], 0.05, 0.3, orient)
+    boxes = common.random_boxes(rng, n_boxes, [-3, -3, -2], [3, 3, 2], 0.05 if n_boxes == 40 else 0.02, 0.3 if n_boxes == 40 else 0.12, orient)
     n = 700
     st = np.zeros((7 + J, n))
     st[0:3] = rng.uniform(-1.5, 1.5, (3, n))
+    if n_boxes > 40:
+        st[2, ::9] += 3.0   # some states above the boxes: lanes the grid cannot answer, next to lanes it can
     st[3:7] = common.random_unit_quats(rng, n) if orient == "so3" else common.yaw_quats(rng.uniform(-np.pi, np.pi, n))
     st[7:] = rng.uniform(-1.4, 1.4, (J, n))
     ref = O.avoid_batch(model, boxes, params, st, 0.01, 0.08, 0.05, True)
@@ -35,7 +40,7 @@ def test_avoidance_rows_match_the_oracle(kind, n_links, orient):
     eng.close()
 
     assert np.array_equal(got["ok"], ref["ok"])
-    assert 0.1 < ref["ok"].mean() < 0.999
+    assert 0.05 < ref["ok"].mean() < 0.999
     assert np.allclose(got["dist"], ref["dist"], rtol=1e-5, atol=1e-9)
     tie = np.abs(got["dist"] - ref["dist"]) > 0   # equal-distance boxes may order differently only at exact ties
     assert np.all((got["box"] == ref["box"]) | tie)

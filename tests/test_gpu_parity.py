@@ -66,6 +66,41 @@ def test_c2_hydrus6_se3_vs_oracle():
     print("c2/se3:", r)
 
 
+def test_distance_grid_lanes_mixed_with_sweep_lanes():
+    """1000-box scenes take their minimum distances from the distance grid; states the grid
+    cannot answer (far from every box, outside its volume, beyond the fp32 range of the lower bounds) fall
+    back to the sweep over all boxes inside the same wave: both kinds, interleaved lane by lane"""
+    w = common.config2k(n=6000)
+    st = w.soa
+    st[0, 0::5] += 30.0        # far outside the grid volume
+    st[2, 1::7] = 3.4          # above the obstacle volume: nearest box farther than the grid's slack for most
+    st[0, 2::11] = 100.0       # beyond the range the fp32 bounds are trusted for
+    st[1, 3::13] = -2.9        # just outside the boxes' bounding volume
+    r = check_against_oracle(w, 6000)
+    print("c2k mixed:", r)
+    # boxes clustered in one corner: most of the sampled volume is far from every box
+    w = common.config2k(n=4000)
+    w.boxes[:, 0:3] = w.boxes[:, 0:3] * 0.35 + np.array([3.0, 1.2, 1.2])
+    r = check_against_oracle(w, 4000)
+    print("c2k clustered:", r)
+
+
+def test_distance_grid_and_sweep_give_identical_distances(monkeypatch):
+    """the grid only changes WHICH pairs reach the fp64 narrowphase, never the value of the closest one: at a
+    size the oracle does not reach, the distances with and without it are the same bits"""
+    for make, n in ((common.config2k, 150000), (common.config3, 100000), (common.config5, 100000)):
+        w = make(n=n)
+        w.soa[0, 0::17] += 2.5   # a share of lanes the grid cannot answer in every wave
+        out = []
+        for off in ("0", "1"):
+            monkeypatch.setenv("MVK_NO_DISTANCE_GRID", off)
+            eng = mp.Engine(w.model, w.boxes, w.params)
+            out.append(eng.eval_batch(w.soa, w.layout))
+            eng.close()
+        assert np.array_equal(out[0]["min_dist"], out[1]["min_dist"]), w.name
+        assert np.array_equal(out[0]["flags"], out[1]["flags"]) and np.array_equal(out[0]["band"], out[1]["band"])
+
+
 def test_c3_dragon4_vs_oracle():
     r = check_against_oracle(common.config3(n=4000), 4000)
     print("c3:", r)
