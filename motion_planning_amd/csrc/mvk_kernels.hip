@@ -258,30 +258,35 @@ DEV double box_box_sat(const double t[3], const double R[9], const double a[3], 
   return best;
 }
 
+// squared distance from edge e (0..11: axis e >> 2, signs from bits 0 and 1) of box A (centre c, axes = columns of
+// R, half extents a; in B's frame) to solid B = [-b,b]^3.  Columns are selected by comparisons on e, no dynamic
+// register indexing, whether e is wave-uniform or per lane.
+DEV double box_edge_to_box2(int e, const double c[3], const double R[9], const double a[3], const double b[3]) {
+  const int ax = e >> 2;
+  const double su = (e & 1) ? 1.0 : -1.0, sv = (e & 2) ? 1.0 : -1.0;
+  double p0[3], d[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double cx = R[3 * k], cy = R[3 * k + 1], cz = R[3 * k + 2];
+    const double Aax = ax == 0 ? cx : (ax == 1 ? cy : cz);
+    const double Au = ax == 0 ? cy : (ax == 1 ? cz : cx);
+    const double Av = ax == 0 ? cz : (ax == 1 ? cx : cy);
+    const double hax = ax == 0 ? a[0] : (ax == 1 ? a[1] : a[2]);
+    const double hu = ax == 0 ? a[1] : (ax == 1 ? a[2] : a[0]);
+    const double hv = ax == 0 ? a[2] : (ax == 1 ? a[0] : a[1]);
+    const double mid = fma(su * hu, Au, fma(sv * hv, Av, c[k]));
+    p0[k] = fma(-hax, Aax, mid);
+    d[k] = 2.0 * hax * Aax;
+  }
+  return seg_box_dist2(p0, d, b);
+}
+
 // min over the 12 edges of box A (in B's frame) of the squared distance to solid B
 DEV double box_edges_to_box2(const double c[3], const double R[9], const double a[3], const double b[3]) {
   double best = INFINITY;
 #pragma unroll 1
-  for (int e = 0; e < 12; ++e) {  // rolled on purpose: 12 copies of seg_box_dist2 would bloat the kernel
-    const int ax = e >> 2;
-    const double su = (e & 1) ? 1.0 : -1.0, sv = (e & 2) ? 1.0 : -1.0;
-    double p0[3], d[3];
-    // columns selected by wave-uniform ax without dynamic register indexing
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double cx = R[3 * k], cy = R[3 * k + 1], cz = R[3 * k + 2];
-      const double Aax = ax == 0 ? cx : (ax == 1 ? cy : cz);
-      const double Au = ax == 0 ? cy : (ax == 1 ? cz : cx);
-      const double Av = ax == 0 ? cz : (ax == 1 ? cx : cy);
-      const double hax = ax == 0 ? a[0] : (ax == 1 ? a[1] : a[2]);
-      const double hu = ax == 0 ? a[1] : (ax == 1 ? a[2] : a[0]);
-      const double hv = ax == 0 ? a[2] : (ax == 1 ? a[0] : a[1]);
-      const double mid = fma(su * hu, Au, fma(sv * hv, Av, c[k]));
-      p0[k] = fma(-hax, Aax, mid);
-      d[k] = 2.0 * hax * Aax;
-    }
-    best = fmin(best, seg_box_dist2(p0, d, b));
-  }
+  for (int e = 0; e < 12; ++e)  // rolled on purpose: 12 copies of seg_box_dist2 would bloat the kernel
+    best = fmin(best, box_edge_to_box2(e, c, R, a, b));
   return best;
 }
 
@@ -387,13 +392,20 @@ constexpr int kItemCap = 4 * kBlock;  // flag path: fp64 (state, box) pairs per 
 typedef __attribute__((address_space(3))) double lds_double;
 typedef __attribute__((address_space(3))) unsigned short lds_ushort;
 typedef __attribute__((address_space(3))) unsigned lds_uint;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(3))) float lds_float;
 struct Smem {
   // [2*J][kBlock] cos/sin of the planned joints, lane-contiguous
   lds_double* cs;
   // [list length][kBlock] candidate obstacle ids
   lds_ushort* list;
+  // full path: this wave's batch of box pairs awaiting their exact distance, [kExactBatch][kExactItem] and the
+  // running minimum of each pair's 24 edge-to-box squared distances (bits of a non-negative double), [kExactBatch]
+  lds_double* ex_item;
+  lds_u64* ex_res;
 };
+constexpr int kExactBatch = 16;  // box pairs whose exact distance one wave computes together
+constexpr int kExactItem = 16;   // doubles per pair: relative rotation 9, centre 3, box half extents 3, pad
 
 // gimbal (roll, pitch) that turn the thrust axis onto the CoG z axis
 // (Dragon::HydrusLikeRobotModel).  zl = CoG z axis in the link frame.
@@ -1260,7 +1272,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
                         const DevObs* __restrict__ obs, const double pos[3], const double Rw[9], const Smem& sm,
                         bool live) {
   using S = Shape<ROBOT, NL>;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   double R[9], p[3];
 #pragma unroll
   for (int k = 0; k < 9; ++k) R[k] = Rw[k];
@@ -1358,8 +1370,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
         // The exact box-box separation (24 edge-to-box distances) costs ~30x the separating-axis bound, and
         // only the few candidates whose bound undercuts the running minimum need it.  Lanes therefore scan
         // their lists with the bound alone, each stopping at its next candidate that does need the exact
-        // distance, and the wave then runs the exact code once for all of them: the wave executes it
-        // max-over-lanes(exact calls) times instead of max-over-lanes(list length) times.
+        // distance; the wave then computes those together (below).
         const double a[3] = {d0, d1, d2};
         int e = 0;
 #pragma unroll 1
@@ -1379,7 +1390,57 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
             else need = g < mind;
             ++e;
           }
-          if (need) mind = fmin(mind, box_box_exact(t, Rr, a, h));
+          // the exact distances, kExactBatch pairs at a time over the whole wave: the pairs go to LDS and every
+          // lane takes (pair, edge) items -- 24 edge-to-box distances per pair, 12 edges of either box against
+          // the other -- merging into the pair's minimum with an LDS atomic.  A wave with E pairs pending runs
+          // ceil(24 E / 64) edge distances per lane instead of 24.
+          unsigned long long pend = __ballot(need);
+#pragma unroll 1
+          while (pend) {
+            const int rank = __popcll(pend & ((1ull << lane) - 1ull));
+            const bool mine = need && ((pend >> lane) & 1ull) && rank < kExactBatch;
+            const int E = min(static_cast<int>(__popcll(pend)), kExactBatch);
+            if (mine) {
+#pragma unroll
+              for (int c = 0; c < 9; ++c) sm.ex_item[rank * kExactItem + c] = Rr[c];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { sm.ex_item[rank * kExactItem + 9 + c] = t[c]; sm.ex_item[rank * kExactItem + 12 + c] = h[c]; }
+              sm.ex_res[rank] = 0x7FF0000000000000ull;  // +inf
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (int it = lane; it < 24 * E; it += 64) {
+              const int pr = it / 24, ed = it - 24 * pr;
+              double iR[9], it_[3], ih[3];
+#pragma unroll
+              for (int c = 0; c < 9; ++c) iR[c] = sm.ex_item[pr * kExactItem + c];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { it_[c] = sm.ex_item[pr * kExactItem + 9 + c]; ih[c] = sm.ex_item[pr * kExactItem + 12 + c]; }
+              // edges 0..11: the primitive's edges against the box (box frame); 12..23: the box's edges against
+              // the primitive (primitive frame: rotation transposed, centre -R^T t), as box_box_exact
+              const bool second = ed >= 12;
+              double cR[9], cc[3], ca[3], cb[3];
+#pragma unroll
+              for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) cR[3 * r + c] = second ? iR[3 * c + r] : iR[3 * r + c];
+                const double tb = -fma(iR[r], it_[0], fma(iR[3 + r], it_[1], iR[6 + r] * it_[2]));
+                cc[r] = second ? tb : it_[r];
+                ca[r] = second ? ih[r] : a[r];
+                cb[r] = second ? a[r] : ih[r];
+              }
+              const double s2 = box_edge_to_box2(second ? ed - 12 : ed, cc, cR, ca, cb);
+              __hip_atomic_fetch_min(&sm.ex_res[pr], static_cast<unsigned long long>(__double_as_longlong(s2)), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (mine) mind = fmin(mind, sqrt(__longlong_as_double(static_cast<long long>(sm.ex_res[rank]))));
+            pend &= ~__ballot(mine);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
         }
       } else {
 #pragma unroll 1
@@ -1952,7 +2013,10 @@ full_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* 
   constexpr int NJ = S::kJoint;
   __shared__ double sm_cs[2 * NJ * kBlock];
   __shared__ unsigned short sm_list[kListCap * kBlock];
-  Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list};
+  __shared__ double sm_ex_item[(kBlock / 64) * kExactBatch * kExactItem];
+  __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kExactBatch];
+  Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list, (lds_double*)sm_ex_item + (threadIdx.x >> 6) * kExactBatch * kExactItem,
+          (lds_u64*)sm_ex_res + (threadIdx.x >> 6) * kExactBatch};
 
   const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool in_range = gi < A.n;
