@@ -223,8 +223,10 @@ DEV double seg_box_dist2(const double p0[3], const double d[3], const double h[3
 // METRIC: gaps of the 9 edge-edge axes are divided by the axis length so the
 // result is the largest metric gap (> 0 separated, <= 0: -penetration depth).
 // Otherwise only its sign is meaningful.
+// `cutoff` (METRIC): once the six face axes alone reach it the nine edge axes are skipped -- the caller only asks
+// whether the gap undercuts cutoff.
 template <bool METRIC>
-DEV double box_box_sat(const double t[3], const double R[9], const double a[3], const double b[3]) {
+DEV double box_box_sat(const double t[3], const double R[9], const double a[3], const double b[3], double cutoff = INFINITY) {
   double Q[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) Q[i] = fabs(R[i]);
@@ -240,6 +242,7 @@ DEV double box_box_sat(const double t[3], const double R[9], const double a[3], 
     const double g = fabs(proj) - (a[j] + fma(b[0], Q[j], fma(b[1], Q[3 + j], b[2] * Q[6 + j])));
     best = fmax(best, g);
   }
+  if (METRIC && best >= cutoff) return best;
 #pragma unroll
   for (int i = 0; i < 3; ++i)  // axes  B_i x A_j
 #pragma unroll
@@ -815,7 +818,7 @@ DEV double narrow(int type, const double PR[9], double d0, double d1, double d2,
     box_rel(O, PR, Rr);
     const double a[3] = {d0, d1, d2};
     if (SIGNED) {
-      d = box_box_sat<true>(t, Rr, a, O.h);
+      d = box_box_sat<true>(t, Rr, a, O.h, cutoff);
       if (d > 0.0 && d < cutoff) d = box_box_exact(t, Rr, a, O.h);
     } else {
       d = box_box_sat<false>(t, Rr, a, O.h);
@@ -1385,7 +1388,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
             to_box_frame(O, pc, t);
             box_rel(O, PR, Rr);
             h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
-            const double g = box_box_sat<true>(t, Rr, a, h);
+            const double g = box_box_sat<true>(t, Rr, a, h, mind);
             if (g <= 0.0) mind = fmin(mind, g);
             else need = g < mind;
             ++e;
@@ -1488,7 +1491,7 @@ DEV double narrow_cp(int type, const double PR[9], double d0, double d1, double 
     for (int c = 0; c < 3; ++c)
       Rr[3 * r + c] = fma(O.R[r], PR[c], fma(O.R[3 + r], PR[3 + c], O.R[6 + r] * PR[6 + c]));
   const double a[3] = {d0, d1, d2};
-  double d = box_box_sat<true>(t, Rr, a, O.h);
+  double d = box_box_sat<true>(t, Rr, a, O.h, cutoff);
   if (!(d > 0.0) || d >= cutoff) return d;  // in contact, or the separating-axis bound cannot beat the caller's minimum
   double pa1[3], pb1[3], pa2[3], pb2[3];
   const double s1 = box_edges_to_box_cp2(t, Rr, a, O.h, pa1, pb1);  // pa1 on the robot, pb1 on the box
