@@ -44,7 +44,16 @@ __device__ unsigned long long g_prof[48];
 #define PROF_LANES(idx, pred) do { const unsigned long long b__ = __ballot(pred); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_prof[idx], (unsigned long long)__popcll(b__)); } while (0)
 #define PROF_WAVE(idx) do { if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&g_prof[idx], 1ull); } while (0)
 #define PROF_SUM(idx, val) do { unsigned long long v__ = (unsigned long long)(val); for (int o__ = 32; o__; o__ >>= 1) v__ += __shfl_xor(v__, o__); if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[idx], v__); } while (0)
+// stage clocks: accumulated per wave in registers (PROF_ACC_DECL in the function), one atomic per stage at PROF_ACC_FLUSH
+#define PROF_ACC_DECL unsigned long long prof_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_T0(var) const unsigned long long var = wall_clock64()
+#define PROF_CLK(slot, var) do { prof_acc__[slot] += wall_clock64() - (var); } while (0)
+#define PROF_ACC_FLUSH(base) do { if ((threadIdx.x & 63) == 0) { for (int i__ = 0; i__ < 8; ++i__) if (prof_acc__[i__]) atomicAdd(&g_prof[(base) + i__], prof_acc__[i__]); } } while (0)
 #else
+#define PROF_ACC_DECL do { } while (0)
+#define PROF_T0(var) do { } while (0)
+#define PROF_CLK(slot, var) do { } while (0)
+#define PROF_ACC_FLUSH(base) do { } while (0)
 #define PROF_LANES(idx, pred) do { } while (0)
 #define PROF_SUM(idx, val) do { } while (0)
 #define PROF_WAVE(idx) do { } while (0)
@@ -1288,6 +1297,8 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
   // boxes that can undercut that bound, and a lane needs the sweep over all boxes only when the whole robot
   // is farther from every box than the grid's slack.
   double upper = INFINITY;
+  PROF_ACC_DECL;
+  PROF_T0(t_w1);
   if (use_grid) {
 #pragma unroll 1
     for (int k = 0; k < S::kSeg; ++k) {
@@ -1304,6 +1315,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
     for (int k = 0; k < 9; ++k) R[k] = Rw[k];
     p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
   }
+  PROF_CLK(0, t_w1);
 #pragma unroll 1
   for (int k = 0; k < S::kSeg; ++k) {
     if (k > 0) advance_frame(M, sm, tid, k, R, p);
@@ -1318,6 +1330,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
 
       // -- broadphase --------------------------------------------------------
+      PROF_T0(t_bp);
       const bool sphere = type == MVK_PRIM_SPHERE;
       int cnt = 0;
       bool scan = live;  // lanes whose candidates come from the sweep over all boxes
@@ -1368,7 +1381,11 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       const bool overflow = cnt > kListCap;
       int todo = live ? (overflow ? A.n_obs : cnt) : 0;
       if (sphere && swept) todo = 0;
+#ifdef MVK_PROF_COUNTS
       PROF_LANES(30, live); PROF_LANES(31, live && scan); PROF_LANES(32, live && overflow); PROF_SUM(33, live ? cnt : 0);
+#endif
+      PROF_CLK(1, t_bp);
+      PROF_T0(t_dr);
       if (type == MVK_PRIM_BOX) {
         // The exact box-box separation (24 edge-to-box distances) costs ~30x the separating-axis bound, and
         // only the few candidates whose bound undercuts the running minimum need it.  Lanes therefore scan
@@ -1398,6 +1415,11 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
           // the other -- merging into the pair's minimum with an LDS atomic.  A wave with E pairs pending runs
           // ceil(24 E / 64) edge distances per lane instead of 24.
           unsigned long long pend = __ballot(need);
+          PROF_T0(t_ex);
+#ifdef MVK_PROF_COUNTS
+          PROF_SUM(34, need ? 1 : 0);
+          if (pend) PROF_WAVE(35);
+#endif
 #pragma unroll 1
           while (pend) {
             const int rank = __popcll(pend & ((1ull << lane) - 1ull));
@@ -1444,6 +1466,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
           }
+          PROF_CLK(3, t_ex);
         }
       } else {
 #pragma unroll 1
@@ -1457,8 +1480,10 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
           }
         }
       }
+      PROF_CLK(2, t_dr);
     }
   }
+  PROF_ACC_FLUSH(20);
   return mind;
 }
 
@@ -2008,8 +2033,11 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 #endif
 }
 
+// Two waves per SIMD on purpose: left alone the compiler takes 256 VGPRs + 50 AGPRs, one wave per SIMD, and
+// every dependent gather of the distance walk (cell -> ids -> boxes) is exposed.  Fitting 256 registers costs
+// 40-110 spilled VGPRs and still runs 1.4-1.5x faster; three waves spill 140-240 and gain nothing more.
 template <int ROBOT, int NL>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 2)
 full_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
             const DevObs* __restrict__ obs) {
   using S = Shape<ROBOT, NL>;
@@ -2034,10 +2062,17 @@ full_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* 
   double thrust[NL];
   double Rw[9];
   bool finite;
+  PROF_ACC_DECL;
+  PROF_T0(t_mu);
   model_update<ROBOT, NL, true>(A, M, X, st, sm, li, o, Rw, finite, thrust);
+  PROF_CLK(4, t_mu);
 
   double mind = INFINITY;
+  PROF_T0(t_cf);
   if (A.do_coll && A.n_obs > 0 && __any(finite)) mind = collide_full<ROBOT, NL>(A, M, X, obs, st, Rw, sm, finite);
+  PROF_CLK(5, t_cf);
+  PROF_ACC_FLUSH(20);
+  PROF_WAVE(28);
   o.min_dist = (A.do_coll && finite) ? mind : INFINITY;
   o.collision = A.do_coll && (mind <= 0.0);
   o.valid = finite && (!A.do_stab || o.stable) && !o.collision;

@@ -11,7 +11,7 @@ import common
 import motion_planning_amd as mp
 lib = mp.abi.load()
 n = 1 << 18
-for name in sys.argv[1:] or ["c2k", "c3", "c5"]:
+for name in sys.argv[1:] or ["c2", "c2k", "c3", "c5"]:
     w = {"c2": common.config2, "c2k": common.config2k, "c3": common.config3, "c5": common.config5}[name](n=n)
     eng = mp.Engine(w.model, w.boxes, w.params)
     d = torch.from_numpy(w.soa).cuda()
@@ -24,6 +24,9 @@ for name in sys.argv[1:] or ["c2k", "c3", "c5"]:
     lib.mvk_debug_prof(buf, 1)
     b = [int(x) for x in buf]
     print(f"{name} full : lane-prims {b[30]}, swept {b[31]} ({b[31] / max(b[30], 1):.4f}), overflow {b[32]} ({b[32] / max(b[30], 1):.4f}), mean candidates {b[33] / max(b[30], 1):.2f}")
+    wv = max(b[28], 1)
+    print(f"{name} full : per wave, us: model update {b[24] / wv / 100:.1f}, collision {b[25] / wv / 100:.1f} = first walk {b[20] / wv / 100:.1f} + candidates {b[21] / wv / 100:.1f}"
+          f" + drain {b[22] / wv / 100:.1f} (of which exact stage {b[23] / wv / 100:.1f}); exact pairs per state {b[34] / n:.2f}, exact rounds per wave {b[35] / wv:.1f}; waves {wv}")
     P = w.model.n_prim
     outs = dict(dist=torch.zeros(P, n, dtype=torch.float64, device="cuda"), ok=torch.zeros(n, dtype=torch.uint8, device="cuda"))
     eng.collision_avoidance_batch_dev(d, w.layout, outs)
