@@ -1184,47 +1184,82 @@ DEV bool grid_collect(const EvalArgs& A, const Smem& sm, bool on, const double p
 // ascending box order.  The fp32 error bound pads both, as in grid_candidates.
 DEV float bcast_lane(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
+constexpr int kSweepChunk = 8;  // lanes served per pass over the boxes
+
 DEV void sweep_for_lanes_f32(const EvalArgs& A, const Smem& sm, bool scan, const double pc[3], double rb, double bound, int& cnt) {
   const int tid = threadIdx.x, lane = tid & 63, wave_tid = tid - lane;
   const unsigned long long todo = __ballot(scan);
   if (todo == 0ull) return;
   const DevObsF* __restrict__ obsf = A.obsf;
   const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
+  // pass 1, kSweepChunk served lanes per pass over the boxes: their running minima are independent chains, and
+  // the wave reductions come once per chunk, not once per box round
   float up2 = INFINITY;
 #pragma unroll 1
-  for (int b = 0; b < A.n_obs; b += 64) {
-    const DevObsF F = obsf[b + lane < A.n_obs ? b + lane : A.n_obs];  // past the end: the padding id's far box
-#pragma unroll 1
-    for (unsigned long long m = todo; m; m &= m - 1ull) {
-      const int src = __ffsll(static_cast<long long>(m)) - 1;
-      float d2 = point_box_dist2_f32(F, bcast_lane(x, src), bcast_lane(y, src), bcast_lane(z, src));
+  for (unsigned long long rem = todo; rem;) {
+    int src[kSweepChunk];
+    float cx[kSweepChunk], cy[kSweepChunk], cz[kSweepChunk], acc[kSweepChunk];
+    int ns = 0;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) d2 = fminf(d2, __shfl_xor(d2, o));
-      if (lane == src) up2 = fminf(up2, d2);
+    for (int j = 0; j < kSweepChunk; ++j) {
+      if (rem) { src[j] = __ffsll(static_cast<long long>(rem)) - 1; rem &= rem - 1ull; ns = j + 1; }
+      else src[j] = src[j > 0 ? j - 1 : 0];  // unused slot (j >= ns, wave-uniform)
+      cx[j] = bcast_lane(x, src[j]); cy[j] = bcast_lane(y, src[j]); cz[j] = bcast_lane(z, src[j]);
+      acc[j] = INFINITY;
     }
+#pragma unroll 1
+    for (int b = 0; b < A.n_obs; b += 64) {
+      const DevObsF F = obsf[b + lane < A.n_obs ? b + lane : A.n_obs];  // past the end: the padding id's far box
+#pragma unroll
+      for (int j = 0; j < kSweepChunk; ++j)
+        if (j < ns) acc[j] = fminf(acc[j], point_box_dist2_f32(F, cx[j], cy[j], cz[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < kSweepChunk; ++j)
+      if (j < ns) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[j] = fminf(acc[j], __shfl_xor(acc[j], o));
+        if (lane == src[j]) up2 = acc[j];
+      }
   }
   const double up = static_cast<double>(sqrtf(up2)) * 1.000001 + static_cast<double>(A.f32_delta);
   const double thr = rb + fmax(fmin(bound, up), 0.0);
   const float tf = (static_cast<float>(thr) + A.f32_delta) * 1.000001f;
   const float thr2f = tf * tf;
+  // pass 2: candidates of each served lane, ascending box order
   int n = 0;
 #pragma unroll 1
-  for (int b = 0; b < A.n_obs; b += 64) {
-    const bool real = b + lane < A.n_obs;
-    const DevObsF F = obsf[real ? b + lane : A.n_obs];
-#pragma unroll 1
-    for (unsigned long long m = todo; m; m &= m - 1ull) {
-      const int src = __ffsll(static_cast<long long>(m)) - 1;
-      const float d2 = point_box_dist2_f32(F, bcast_lane(x, src), bcast_lane(y, src), bcast_lane(z, src));
-      const bool pass = real && d2 <= bcast_lane(thr2f, src);
-      const unsigned long long pm = __ballot(pass);
-      const int at = __builtin_amdgcn_readlane(n, src);
-      if (pass) {
-        const int slot = at + __popcll(pm & ((1ull << lane) - 1ull));
-        if (slot < kListCap) sm.list[slot * kBlock + wave_tid + src] = static_cast<unsigned short>(b + lane);
-      }
-      if (lane == src) n += __popcll(pm);
+  for (unsigned long long rem = todo; rem;) {
+    int src[kSweepChunk], cn[kSweepChunk];
+    float cx[kSweepChunk], cy[kSweepChunk], cz[kSweepChunk], ct[kSweepChunk];
+    int ns = 0;
+#pragma unroll
+    for (int j = 0; j < kSweepChunk; ++j) {
+      if (rem) { src[j] = __ffsll(static_cast<long long>(rem)) - 1; rem &= rem - 1ull; ns = j + 1; }
+      else src[j] = src[j > 0 ? j - 1 : 0];
+      cx[j] = bcast_lane(x, src[j]); cy[j] = bcast_lane(y, src[j]); cz[j] = bcast_lane(z, src[j]);
+      ct[j] = bcast_lane(thr2f, src[j]);
+      cn[j] = 0;
     }
+#pragma unroll 1
+    for (int b = 0; b < A.n_obs; b += 64) {
+      const bool real = b + lane < A.n_obs;
+      const DevObsF F = obsf[real ? b + lane : A.n_obs];
+#pragma unroll
+      for (int j = 0; j < kSweepChunk; ++j) {
+        if (j < ns) {
+          const bool pass = real && point_box_dist2_f32(F, cx[j], cy[j], cz[j]) <= ct[j];
+          const unsigned long long pm = __ballot(pass);
+          if (pass) {
+            const int slot = cn[j] + __popcll(pm & ((1ull << lane) - 1ull));
+            if (slot < kListCap) sm.list[slot * kBlock + wave_tid + src[j]] = static_cast<unsigned short>(b + lane);
+          }
+          cn[j] += __popcll(pm);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kSweepChunk; ++j) if (j < ns && lane == src[j]) n = cn[j];
   }
   if (scan) cnt = n;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1488,6 +1523,32 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
 }
 
 
+// exact separation of two disjoint boxes with the closest points (A: centre t, axes Rr, half extents a, in the
+// frame of B = [-h,h]^3): pr on A, pe on B, both in B's frame
+DEV double box_box_exact_cp(const double t[3], const double Rr[9], const double a[3], const double h[3], double pr[3], double pe[3]) {
+  double pa1[3], pb1[3], pa2[3], pb2[3];
+  const double s1 = box_edges_to_box_cp2(t, Rr, a, h, pa1, pb1);  // pa1 on the robot, pb1 on the box
+  double Rt[9], tb[3];  // the box in the primitive's frame
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Rt[3 * r + c] = Rr[3 * c + r];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) tb[r] = -fma(Rr[r], t[0], fma(Rr[3 + r], t[1], Rr[6 + r] * t[2]));
+  const double s2 = box_edges_to_box_cp2(tb, Rt, h, a, pa2, pb2);  // pa2 on the box, pb2 on the robot (primitive frame)
+  if (s1 <= s2) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pr[c] = pa1[c]; pe[c] = pb1[c]; }
+    return sqrt(s1);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {  // primitive frame -> box frame: x_B = Rr x_A + t
+    pe[c] = fma(Rr[3 * c], pa2[0], fma(Rr[3 * c + 1], pa2[1], fma(Rr[3 * c + 2], pa2[2], t[c])));
+    pr[c] = fma(Rr[3 * c], pb2[0], fma(Rr[3 * c + 1], pb2[1], fma(Rr[3 * c + 2], pb2[2], t[c])));
+  }
+  return sqrt(s2);
+}
+
 // signed distance of one primitive to one box with the nearest points (box frame): pr on the robot
 // primitive, pe on the box.  Points are NaN when the pair is in contact (distance <= 0).
 DEV double narrow_cp(int type, const double PR[9], double d0, double d1, double d2, const DevObs& O, const double t[3],
@@ -1518,27 +1579,7 @@ DEV double narrow_cp(int type, const double PR[9], double d0, double d1, double 
   const double a[3] = {d0, d1, d2};
   double d = box_box_sat<true>(t, Rr, a, O.h, cutoff);
   if (!(d > 0.0) || d >= cutoff) return d;  // in contact, or the separating-axis bound cannot beat the caller's minimum
-  double pa1[3], pb1[3], pa2[3], pb2[3];
-  const double s1 = box_edges_to_box_cp2(t, Rr, a, O.h, pa1, pb1);  // pa1 on the robot, pb1 on the box
-  double Rt[9], tb[3];  // the box in the primitive's frame
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Rt[3 * r + c] = Rr[3 * c + r];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) tb[r] = -fma(Rr[r], t[0], fma(Rr[3 + r], t[1], Rr[6 + r] * t[2]));
-  const double s2 = box_edges_to_box_cp2(tb, Rt, O.h, a, pa2, pb2);  // pa2 on the box, pb2 on the robot (primitive frame)
-  if (s1 <= s2) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { pr[c] = pa1[c]; pe[c] = pb1[c]; }
-    return sqrt(s1);
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {  // primitive frame -> box frame: x_B = Rr x_A + t
-    pe[c] = fma(Rr[3 * c], pa2[0], fma(Rr[3 * c + 1], pa2[1], fma(Rr[3 * c + 2], pa2[2], t[c])));
-    pr[c] = fma(Rr[3 * c], pb2[0], fma(Rr[3 * c + 1], pb2[1], fma(Rr[3 * c + 2], pb2[2], t[c])));
-  }
-  return sqrt(s2);
+  return box_box_exact_cp(t, Rr, a, O.h, pr, pe);
 }
 
 // ------------------------------------------------------------------------
@@ -2156,7 +2197,7 @@ full_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* 
 // the normal from the environment to the robot (:255), the row n^T J_lin over
 // [root v (world), root w (world), planned joints] (:259-260) and the damped bound (:262-265).
 template <int ROBOT, int NL>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 2)  // as the full kernel: occupancy over spills
 avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
              const DevObs* __restrict__ obs) {
   using S = Shape<ROBOT, NL>;
@@ -2187,6 +2228,7 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   for (int k = 0; k < 9; ++k) R[k] = Rw[k];
   p[0] = st[0]; p[1] = st[1]; p[2] = st[2];
   bool ok = true;
+  PROF_ACC_DECL;
   const bool use_grid = A.dgrid.start != nullptr;
   const bool f32_safe = fmax(fabs(st[0]), fmax(fabs(st[1]), fabs(st[2]))) + X->reach <= A.f32_range;
 #pragma unroll 1
@@ -2201,6 +2243,7 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
       const double rb = X->prim_bound[q];
       const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+      PROF_T0(t_c);
       int cnt = 0;
       if (use_grid) {
         bool scan = in_range;
@@ -2210,7 +2253,9 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
         sweep_for_lanes_f32(A, sm, scan && f32_safe, pc, rb, INFINITY, cnt);
         const bool slow = scan && !f32_safe;
         sweep_for_lanes(A, obs, sm, slow, pc, rb, INFINITY, b2, c2);
+#ifdef MVK_PROF_COUNTS
         PROF_LANES(37, scan);
+#endif
         if (slow) cnt = c2;
       } else {
         auto centre_dist2 = [&](const DevObs& O) {
@@ -2234,28 +2279,117 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       }
       const bool overflow = cnt > kListCap;
       const int todo = (use_grid && !in_range) ? 0 : (overflow ? A.n_obs : cnt);
+      PROF_CLK(0, t_c);
+      PROF_T0(t_d);
+#ifdef MVK_PROF_COUNTS
       PROF_LANES(36, in_range); PROF_LANES(38, in_range && overflow); PROF_SUM(39, in_range ? cnt : 0);
+#endif
       double best = INFINITY, br[3] = {NAN, NAN, NAN}, be[3] = {NAN, NAN, NAN};
       int bi = -1;
-#pragma unroll 1
-      for (int e = 0; __any(e < todo); ++e) {
-        if (e < todo) {
-          const int ob = overflow ? e : sm.list[e * kBlock + tid];
-          const DevObs O = obs[ob];
-          double t[3], pr[3], pq[3];
-          to_box_frame(O, pc, t);
-          const double d = narrow_cp(type, PR, d0, d1, d2, O, t, pr, pq, best);
-          if (d < best) {  // ascending box order, strict: the first minimum wins, as in the oracle
+      if (type == MVK_PRIM_BOX) {
+        // Every separated primitive needs at least one exact closest-point computation (24 edge-to-box closest
+        // pairs, ~30x a separating-axis gap), so the order matters: pass A takes the gap of every candidate
+        // (contacts are final there) and finds the smallest; its exact distance comes first and prunes most of the
+        // rest; pass B scans the others with the gap alone, each lane stopping at its next candidate whose gap
+        // still undercuts its minimum, and the wave runs the exact code once per such round.  The oracle keeps
+        // the first minimum in ascending box order: out of order, that is the minimum of (distance, box id).
+        const double a[3] = {d0, d1, d2};
+        auto take = [&](double d, int ob, const DevObs& O, const double pr[3], const double pq[3]) {
+          if (d < best || (d == best && ob < bi)) {
             best = d;
             bi = ob;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {  // box frame -> world
+            for (int c = 0; c < 3; ++c) {  // box frame -> world (NaN points stay NaN)
               br[c] = fma(O.R[3 * c], pr[0], fma(O.R[3 * c + 1], pr[1], fma(O.R[3 * c + 2], pr[2], O.c[c])));
               be[c] = fma(O.R[3 * c], pq[0], fma(O.R[3 * c + 1], pq[1], fma(O.R[3 * c + 2], pq[2], O.c[c])));
             }
           }
+        };
+        const double nan3[3] = {NAN, NAN, NAN};
+        double gmin = INFINITY;
+        int emin = -1;
+        PROF_T0(t_a);
+#pragma unroll 1
+        for (int e = 0; __any(e < todo); ++e) {
+          if (e < todo) {
+            const int ob = overflow ? e : sm.list[e * kBlock + tid];
+            const DevObs& O = obs[ob];
+            double Rr[9], t[3];
+            to_box_frame(O, pc, t);
+            box_rel(O, PR, Rr);
+            const double g = box_box_sat<true>(t, Rr, a, O.h, gmin);
+            if (g <= 0.0) take(g, ob, O, nan3, nan3);  // in contact: no points
+            else if (g < gmin) { gmin = g; emin = e; }
+          }
+        }
+        PROF_CLK(3, t_a);
+        PROF_T0(t_f);
+        {
+          const bool first = emin >= 0 && gmin <= best;
+          if (__any(first)) {
+            if (first) {
+              const int ob = overflow ? emin : sm.list[emin * kBlock + tid];
+              const DevObs O = obs[ob];
+              double Rr[9], t[3], pr[3], pq[3];
+              to_box_frame(O, pc, t);
+              box_rel(O, PR, Rr);
+              const double d = box_box_exact_cp(t, Rr, a, O.h, pr, pq);
+              take(d, ob, O, pr, pq);
+            }
+          }
+        }
+        PROF_CLK(4, t_f);
+        int e = 0;
+#pragma unroll 1
+        while (__any(e < todo)) {
+          bool need = false;
+          int ob_n = 0;
+          double Rr[9], t[3];
+#pragma unroll 1
+          while (e < todo && !need) {
+            if (e != emin) {
+              const int ob = overflow ? e : sm.list[e * kBlock + tid];
+              const DevObs& O = obs[ob];
+              to_box_frame(O, pc, t);
+              box_rel(O, PR, Rr);
+              const double g = box_box_sat<true>(t, Rr, a, O.h, best * (1.0 + 1e-15) + 1e-300);
+              if (g > 0.0 && g <= best) {
+                need = true;
+                ob_n = ob;
+              }
+            }
+            ++e;
+          }
+          if (need) {
+            const DevObs O = obs[ob_n];
+            double pr[3], pq[3];
+            const double d = box_box_exact_cp(t, Rr, a, O.h, pr, pq);
+            take(d, ob_n, O, pr, pq);
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int e = 0; __any(e < todo); ++e) {
+          if (e < todo) {
+            const int ob = overflow ? e : sm.list[e * kBlock + tid];
+            const DevObs O = obs[ob];
+            double t[3], pr[3], pq[3];
+            to_box_frame(O, pc, t);
+            const double d = narrow_cp(type, PR, d0, d1, d2, O, t, pr, pq, best);
+            if (d < best) {  // ascending box order, strict: the first minimum wins, as in the oracle
+              best = d;
+              bi = ob;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {  // box frame -> world
+                br[c] = fma(O.R[3 * c], pr[0], fma(O.R[3 * c + 1], pr[1], fma(O.R[3 * c + 2], pr[2], O.c[c])));
+                be[c] = fma(O.R[3 * c], pq[0], fma(O.R[3 * c + 1], pq[1], fma(O.R[3 * c + 2], pq[2], O.c[c])));
+              }
+            }
+          }
         }
       }
+      PROF_CLK(1, t_d);
+      PROF_T0(t_r);
       const bool usable = bi >= 0 && best > 0.0;
       ok = ok && (bi < 0 || best > 0.0);
       // normal from the environment to the robot, and the row over the chain up to this segment
@@ -2310,8 +2444,11 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
           for (int c = 0; c < W; ++c) A.av_row[(static_cast<uint64_t>(W) * q + c) * A.ld + gi] = row[c];
         }
       }
+      PROF_CLK(2, t_r);
     }
   }
+  PROF_ACC_FLUSH(40);
+  PROF_WAVE(47);
   if (in_range && A.av_ok) A.av_ok[gi] = ok ? 1 : 0;
 }
 
