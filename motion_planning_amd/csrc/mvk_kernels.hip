@@ -336,6 +336,28 @@ DEV double seg_box_closest2(const double p0[3], const double d[3], const double 
   return s;
 }
 
+// closest pair between edge e of box A (in B's frame) and solid B: squared distance, y on the edge, z on B.
+// Edge order of the oracle: axis e >> 2, then the sign of u (bit 1), then the sign of v (bit 0).
+DEV double box_edge_to_box_cp2(int e, const double c[3], const double R[9], const double a[3], const double b[3], double y[3], double z[3]) {
+  const int ax = e >> 2;
+  const double su = (e & 2) ? 1.0 : -1.0, sv = (e & 1) ? 1.0 : -1.0;
+  double p0[3], d[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double cx = R[3 * k], cy = R[3 * k + 1], cz = R[3 * k + 2];
+    const double Aax = ax == 0 ? cx : (ax == 1 ? cy : cz);
+    const double Au = ax == 0 ? cy : (ax == 1 ? cz : cx);
+    const double Av = ax == 0 ? cz : (ax == 1 ? cx : cy);
+    const double hax = ax == 0 ? a[0] : (ax == 1 ? a[1] : a[2]);
+    const double hu = ax == 0 ? a[1] : (ax == 1 ? a[2] : a[0]);
+    const double hv = ax == 0 ? a[2] : (ax == 1 ? a[0] : a[1]);
+    const double mid = fma(su * hu, Au, fma(sv * hv, Av, c[k]));
+    p0[k] = fma(-hax, Aax, mid);
+    d[k] = 2.0 * hax * Aax;
+  }
+  return seg_box_closest2(p0, d, b, y, z);
+}
+
 // closest pair between the 12 edges of box A (in B's frame) and solid B: squared distance,
 // pa on A's edge, pb on B (both in B's frame)
 DEV double box_edges_to_box_cp2(const double c[3], const double R[9], const double a[3], const double b[3],
@@ -343,25 +365,8 @@ DEV double box_edges_to_box_cp2(const double c[3], const double R[9], const doub
   double best = INFINITY;
 #pragma unroll 1
   for (int e = 0; e < 12; ++e) {
-    // same edge order as the oracle: axis, then the sign of u, then the sign of v
-    const int ax = e >> 2;
-    const double su = (e & 2) ? 1.0 : -1.0, sv = (e & 1) ? 1.0 : -1.0;
-    double p0[3], d[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double cx = R[3 * k], cy = R[3 * k + 1], cz = R[3 * k + 2];
-      const double Aax = ax == 0 ? cx : (ax == 1 ? cy : cz);
-      const double Au = ax == 0 ? cy : (ax == 1 ? cz : cx);
-      const double Av = ax == 0 ? cz : (ax == 1 ? cx : cy);
-      const double hax = ax == 0 ? a[0] : (ax == 1 ? a[1] : a[2]);
-      const double hu = ax == 0 ? a[1] : (ax == 1 ? a[2] : a[0]);
-      const double hv = ax == 0 ? a[2] : (ax == 1 ? a[0] : a[1]);
-      const double mid = fma(su * hu, Au, fma(sv * hv, Av, c[k]));
-      p0[k] = fma(-hax, Aax, mid);
-      d[k] = 2.0 * hax * Aax;
-    }
     double y[3], z[3];
-    const double s2 = seg_box_closest2(p0, d, b, y, z);
+    const double s2 = box_edge_to_box_cp2(e, c, R, a, b, y, z);
     if (s2 < best) {
       best = s2;
 #pragma unroll
@@ -415,8 +420,13 @@ struct Smem {
   // running minimum of each pair's 24 edge-to-box squared distances (bits of a non-negative double), [kExactBatch]
   lds_double* ex_item;
   lds_u64* ex_res;
+  // avoidance rows: the squared distance of every (pair, edge) item of the batch, [24 * kCpBatch], and the lowest
+  // edge index among each pair's minima, [kCpBatch]
+  lds_double* ex_s2;
+  lds_uint* ex_win;
 };
 constexpr int kExactBatch = 16;  // box pairs whose exact distance one wave computes together
+constexpr int kCpBatch = 8;      // the same for the avoidance rows (closest points as well)
 constexpr int kExactItem = 16;   // doubles per pair: relative rotation 9, centre 3, box half extents 3, pad
 
 // gimbal (roll, pitch) that turn the thrust axis onto the CoG z axis
@@ -2204,8 +2214,14 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   constexpr int NJ = S::kJoint, W = 6 + NJ;
   __shared__ double sm_cs[2 * NJ * kBlock];
   __shared__ unsigned short sm_list[kListCap * kBlock];
-  Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list};
-  const int tid = threadIdx.x;
+  __shared__ double sm_ex_item[(kBlock / 64) * kCpBatch * kExactItem];
+  __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kCpBatch];
+  __shared__ double sm_ex_s2[(kBlock / 64) * 24 * kCpBatch];
+  __shared__ unsigned sm_ex_win[(kBlock / 64) * kCpBatch];
+  const int wv = threadIdx.x >> 6;
+  Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list, (lds_double*)sm_ex_item + wv * kCpBatch * kExactItem, (lds_u64*)sm_ex_res + wv * kCpBatch,
+          (lds_double*)sm_ex_s2 + wv * 24 * kCpBatch, (lds_uint*)sm_ex_win + wv * kCpBatch};
+  const int tid = threadIdx.x, lane = tid & 63;
   const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + tid;
   const bool in_range = gi < A.n;
   const uint64_t li = in_range ? gi : (A.n - 1);
@@ -2360,11 +2376,87 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
             }
             ++e;
           }
-          if (need) {
-            const DevObs O = obs[ob_n];
-            double pr[3], pq[3];
-            const double d = box_box_exact_cp(t, Rr, a, O.h, pr, pq);
-            take(d, ob_n, O, pr, pq);
+          // the pairs that still need the exact closest points -- a few per wave, unlike the first round -- are
+          // computed by the whole wave, kCpBatch at a time: (pair, edge) items over all lanes, an LDS atomic min
+          // per pair over its 24 squared distances, a second one over the edge indices that reach it (the lowest
+          // wins, as in the one-lane form: robot edges before box edges, ascending), and the owner lane repeats
+          // that one edge for its points.  Same arithmetic per edge, so the result keeps its bits.
+          unsigned long long pend = __ballot(need);
+#pragma unroll 1
+          while (pend) {
+            const int rank = __popcll(pend & ((1ull << lane) - 1ull));
+            const bool mine = need && ((pend >> lane) & 1ull) && rank < kCpBatch;
+            const int E = min(static_cast<int>(__popcll(pend)), kCpBatch);
+            double h[3] = {0.0, 0.0, 0.0};
+            if (mine) {
+              const DevObs& O = obs[ob_n];
+              h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
+#pragma unroll
+              for (int c = 0; c < 9; ++c) sm.ex_item[rank * kExactItem + c] = Rr[c];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { sm.ex_item[rank * kExactItem + 9 + c] = t[c]; sm.ex_item[rank * kExactItem + 12 + c] = h[c]; }
+              sm.ex_res[rank] = 0x7FF0000000000000ull;  // +inf
+              sm.ex_win[rank] = 0xFFFFFFFFu;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // one (pair, edge): inputs as box_box_exact_cp builds them for its two halves
+            auto edge_item = [&](const double iR[9], const double it_[3], const double ih[3], int ed, double y[3], double z[3]) {
+              const bool second = ed >= 12;
+              double cR[9], cc[3], ca[3], cb[3];
+#pragma unroll
+              for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) cR[3 * r + c] = second ? iR[3 * c + r] : iR[3 * r + c];
+                const double tb = -fma(iR[r], it_[0], fma(iR[3 + r], it_[1], iR[6 + r] * it_[2]));
+                cc[r] = second ? tb : it_[r];
+                ca[r] = second ? ih[r] : a[r];
+                cb[r] = second ? a[r] : ih[r];
+              }
+              return box_edge_to_box_cp2(second ? ed - 12 : ed, cc, cR, ca, cb, y, z);
+            };
+#pragma unroll 1
+            for (int it = lane; it < 24 * E; it += 64) {
+              const int pr_ = it / 24, ed = it - 24 * pr_;
+              double iR[9], it_[3], ih[3], y[3], z[3];
+#pragma unroll
+              for (int c = 0; c < 9; ++c) iR[c] = sm.ex_item[pr_ * kExactItem + c];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { it_[c] = sm.ex_item[pr_ * kExactItem + 9 + c]; ih[c] = sm.ex_item[pr_ * kExactItem + 12 + c]; }
+              const double s2 = edge_item(iR, it_, ih, ed, y, z);
+              sm.ex_s2[it] = s2;
+              __hip_atomic_fetch_min(&sm.ex_res[pr_], static_cast<unsigned long long>(__double_as_longlong(s2)), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (int it = lane; it < 24 * E; it += 64) {
+              const int pr_ = it / 24, ed = it - 24 * pr_;
+              if (static_cast<unsigned long long>(__double_as_longlong(sm.ex_s2[it])) == sm.ex_res[pr_])
+                __hip_atomic_fetch_min(&sm.ex_win[pr_], static_cast<unsigned>(ed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+              const int ed = static_cast<int>(sm.ex_win[rank]);
+              double y[3], z[3], pr[3], pq[3];
+              const double s2 = edge_item(Rr, t, h, ed, y, z);
+              if (ed < 12) {  // y on the robot's edge, z on the box (box frame)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { pr[c] = y[c]; pq[c] = z[c]; }
+              } else {        // y on the box's edge, z on the robot (primitive frame): x_B = Rr x_A + t
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                  pq[c] = fma(Rr[3 * c], y[0], fma(Rr[3 * c + 1], y[1], fma(Rr[3 * c + 2], y[2], t[c])));
+                  pr[c] = fma(Rr[3 * c], z[0], fma(Rr[3 * c + 1], z[1], fma(Rr[3 * c + 2], z[2], t[c])));
+                }
+              }
+              take(sqrt(s2), ob_n, obs[ob_n], pr, pq);
+            }
+            pend &= ~__ballot(mine);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
           }
         }
       } else {
