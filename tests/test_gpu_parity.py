@@ -101,6 +101,28 @@ def test_distance_grid_and_sweep_give_identical_distances(monkeypatch):
         assert np.array_equal(out[0]["flags"], out[1]["flags"]) and np.array_equal(out[0]["band"], out[1]["band"])
 
 
+def test_candidate_list_overflow_falls_back_to_every_box():
+    """more boxes near one primitive than a lane's candidate list holds (32): the lane then tests every box of the
+    scene for that primitive -- distances, flags and the avoidance rows' nearest box still match the oracle"""
+    rng = np.random.default_rng(77)
+    w = common.config2k(n=1500)
+    cluster = common.random_boxes(rng, 120, [0.8, -0.4, -0.3], [1.6, 0.4, 0.3], 0.01, 0.03, "so3")   # a swarm of small boxes
+    spread = common.random_boxes(rng, 200, [-2.0, -2.2, -2.2], [5.0, 2.2, 2.2], 0.02, 0.2, "yaw")
+    w.boxes = np.concatenate([spread[:100], cluster, spread[100:]])
+    w.soa[0] = rng.uniform(0.0, 2.4, 1500)     # around the swarm
+    w.soa[1] = rng.uniform(-1.0, 1.0, 1500)
+    w.soa[2] = rng.uniform(-0.6, 0.6, 1500)
+    r = check_against_oracle(w, 1500)
+    print("overflow:", r)
+    ref = O.avoid_batch(w.model, w.boxes, w.params, w.soa[:, :400])
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    got = eng.collision_avoidance_batch(w.soa[:, :400], w.layout)
+    eng.close()
+    assert np.allclose(got["dist"], ref["dist"], rtol=1e-5, atol=1e-9)
+    tie = np.abs(got["dist"] - ref["dist"]) > 0
+    assert np.all((got["box"] == ref["box"]) | tie) and np.array_equal(got["ok"], ref["ok"])
+
+
 def test_c3_dragon4_vs_oracle():
     r = check_against_oracle(common.config3(n=4000), 4000)
     print("c3:", r)
