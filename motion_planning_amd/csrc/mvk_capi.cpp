@@ -747,6 +747,7 @@ namespace {
 int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, uint8_t* flags, double* min_dist,
               double* margin, uint8_t* band, const mvk_detail_out* det, bool force_full) {
   if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  if (c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check is in flight on this ctx: call mvk_check_motion_batch_end first");
   if (n == 0) return MVK_OK;
   if (!soa || ld < n) return fail(MVK_ERR_INVALID_ARG, "bad state array (null, or ld < n)");
   const int rows = layout_rows(c, layout);
@@ -756,24 +757,18 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
   const size_t dld = round_up(n, 64);
   const int NL = c->model.n_rotor;
   if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
-  if (flags && !min_dist && !margin && !band && !det && !force_full && n <= (1u << 16)) {
-    // the verdicts of a small batch (down to the single state of an OMPL isValid call): shaped for latency
-    // like the edge checks -- the rows packed into one pinned block, one copy each way, one synchronisation
+  // Small batches (down to the single state of an OMPL isValid call, or the few hundred states of a densified
+  // path) are shaped for latency like the edge checks: the rows packed into one pinned block, the outputs gathered
+  // in another, every copy asynchronous, one synchronisation.  Large ones copy straight from / to the caller's memory.
+  const bool staged = n <= (1u << 16);
+  if (staged) {
     if (int rc = c->pin_up.reserve(dld * rows * sizeof(double))) return rc;
-    if (int rc = c->pin_down.reserve(dld)) return rc;
-    if (int rc = c->flags.reserve(dld)) return rc;
     double* up = static_cast<double*>(c->pin_up.p);
     for (int r = 0; r < rows; ++r) std::memcpy(up + static_cast<size_t>(r) * dld, soa + static_cast<size_t>(r) * ld, n * sizeof(double));
     HIP_TRY(hipMemcpyAsync(c->in_a.p, up, dld * rows * sizeof(double), hipMemcpyHostToDevice, s));
-    if (int rc = run_eval_dev(c, static_cast<const double*>(c->in_a.p), n, dld, layout, static_cast<uint8_t*>(c->flags.p), nullptr,
-                              nullptr, nullptr, nullptr, nullptr, false, s))
-      return rc;
-    HIP_TRY(hipMemcpyAsync(c->pin_down.p, c->flags.p, n, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    std::memcpy(flags, c->pin_down.p, n);
-    return MVK_OK;
+  } else {
+    if (int rc = copy_rows(c->in_a.p, dld, soa, ld, sizeof(double), n, rows, hipMemcpyHostToDevice, s)) return rc;
   }
-  if (int rc = copy_rows(c->in_a.p, dld, soa, ld, sizeof(double), n, rows, hipMemcpyHostToDevice, s)) return rc;
   if (flags) if (int rc = c->flags.reserve(dld)) return rc;
   if (band) if (int rc = c->band.reserve(dld)) return rc;
   if (min_dist) if (int rc = c->mind.reserve(dld * sizeof(double))) return rc;
@@ -799,6 +794,36 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
                             margin ? static_cast<double*>(c->margin.p) : nullptr,
                             band ? static_cast<uint8_t*>(c->band.p) : nullptr, det ? &dd : nullptr, force_full, s))
     return rc;
+  if (staged) {
+    // pinned block: [flags dld][band dld][min_dist dld][margin dld][detail rows, pitch dld]
+    size_t det_total = 0;
+    for (int k = 0; k < 6; ++k) if (host_det[k]) det_total += det_rows[k];
+    if (int rc = c->pin_down.reserve(2 * dld + (2 + det_total) * dld * sizeof(double))) return rc;
+    unsigned char* down = static_cast<unsigned char*>(c->pin_down.p);
+    double* down_d = reinterpret_cast<double*>(down + 2 * dld);
+    if (flags) HIP_TRY(hipMemcpyAsync(down, c->flags.p, n, hipMemcpyDeviceToHost, s));
+    if (band) HIP_TRY(hipMemcpyAsync(down + dld, c->band.p, n, hipMemcpyDeviceToHost, s));
+    if (min_dist) HIP_TRY(hipMemcpyAsync(down_d, c->mind.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (margin) HIP_TRY(hipMemcpyAsync(down_d + dld, c->margin.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    size_t at = 2;
+    for (int k = 0; k < 6; ++k)
+      if (host_det[k]) {
+        HIP_TRY(hipMemcpyAsync(down_d + at * dld, c->det[k].p, det_rows[k] * dld * sizeof(double), hipMemcpyDeviceToHost, s));
+        at += det_rows[k];
+      }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (flags) std::memcpy(flags, down, n);
+    if (band) std::memcpy(band, down + dld, n);
+    if (min_dist) std::memcpy(min_dist, down_d, n * sizeof(double));
+    if (margin) std::memcpy(margin, down_d + dld, n * sizeof(double));
+    at = 2;
+    for (int k = 0; k < 6; ++k)
+      if (host_det[k]) {
+        for (size_t r = 0; r < det_rows[k]; ++r) std::memcpy(host_det[k] + r * ld, down_d + (at + r) * dld, n * sizeof(double));
+        at += det_rows[k];
+      }
+    return MVK_OK;
+  }
   if (flags) HIP_TRY(hipMemcpyAsync(flags, c->flags.p, n, hipMemcpyDeviceToHost, s));
   if (band) HIP_TRY(hipMemcpyAsync(band, c->band.p, n, hipMemcpyDeviceToHost, s));
   if (min_dist) HIP_TRY(hipMemcpyAsync(min_dist, c->mind.p, n * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -12,7 +12,8 @@ for name, w in (("c2 (100 boxes)", common.config2(n=64)), ("c2k (1000 boxes)", c
     eng = mp.Engine(w.model, w.boxes, w.params)
     s = np.ascontiguousarray(w.soa[:, :1])
     for fn, label in ((lambda: eng.is_valid_batch(s, w.layout), "flag path, batch of one"),
-                      (lambda: eng.eval_batch(s, w.layout), "full kernel, batch of one")):
+                      (lambda: eng.is_valid(s[:, 0]), "mvk_is_valid (full kernel: verdict, distance, margin)"),
+                      (lambda: eng.eval_batch(s, w.layout), "full kernel with every detail output, batch of one")):
         for _ in range(10):
             fn()
         t0 = time.perf_counter()
