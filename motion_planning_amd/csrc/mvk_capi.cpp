@@ -291,7 +291,8 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
       lo[k] = std::fmin(lo[k], host[i].c[k] - host[i].bound);
       hi[k] = std::fmax(hi[k], host[i].c[k] + host[i].bound);
     }
-  constexpr int kProbe = 2048;
+  // 2048 probe points, fewer for very large scenes (the probes cost kProbe * n point-to-box distances on the host)
+  const int kProbe = static_cast<int>(std::min<size_t>(2048, std::max<size_t>(256, (size_t{1} << 23) / n)));
   std::vector<double> probe(3 * kProbe), dist(kProbe);
   uint64_t rng = 0x9E3779B97F4A7C15ull;
   for (int i = 0; i < 3 * kProbe; ++i) {
