@@ -119,6 +119,42 @@ def edge_checks(dev):
             "edges_per_s": E / ms * 1e3, "checks_per_s": E * nd / ms * 1e3, "valid_edge_fraction": float(ok.float().mean().item())}
 
 
+def distance_path(eng, w, d_soa, dev):
+    """the same batch through the distance kernels: full path (flags + exact minimum distance + margins + batch
+    statistics) and the collision-avoidance rows (8(f)-3) on the first 262 144 states"""
+    import torch
+    n = d_soa.shape[1]
+    fl = torch.zeros(n, dtype=torch.uint8, device=dev)
+    md = torch.zeros(n, dtype=torch.float64, device=dev)
+    mg = torch.zeros(n, dtype=torch.float64, device=dev)
+
+    def timed(fn, reps=4):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+    full_ms = timed(lambda: eng.is_valid_batch_dev(d_soa, w.layout, d_flags=fl, d_min_dist=md, d_margin=mg))
+    stats = eng.reduce_stats()
+    na = min(n, 1 << 18)
+    P, W = w.model.n_prim, 6 + w.model.n_joint
+    da = d_soa[:, :na].contiguous()
+    outs = dict(dist=torch.zeros(P, na, dtype=torch.float64, device=dev), box=torch.zeros(P, na, dtype=torch.int32, device=dev),
+                p_env=torch.zeros(3 * P, na, dtype=torch.float64, device=dev), p_robot=torch.zeros(3 * P, na, dtype=torch.float64, device=dev),
+                row=torch.zeros(W * P, na, dtype=torch.float64, device=dev), lb=torch.zeros(P, na, dtype=torch.float64, device=dev),
+                ok=torch.zeros(na, dtype=torch.uint8, device=dev))
+    avoid_ms = timed(lambda: eng.collision_avoidance_batch_dev(da, w.layout, outs))
+    return {"full_path": {"states": n, "ms": full_ms, "states_per_s": n / full_ms * 1e3,
+                          "outputs": "flags, min_dist, margin per state + batch statistics",
+                          "min_dist": stats["min_dist"], "min_margin": stats["min_margin"], "valid": stats["valid_count"]},
+            "avoidance_rows": {"states": na, "ms": avoid_ms, "states_per_s": na / avoid_ms * 1e3,
+                               "outputs": "per primitive: distance, nearest box and points, constraint row, bound"}}
+
+
 def pmc_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/latest_pmc.json, written by profiles/summarize.py; FETCH_SIZE already doubled per the
@@ -197,6 +233,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
     ap.add_argument("--no-edges", action="store_true")
+    ap.add_argument("--no-distance", action="store_true", help="skip the distance-kernel leg (full path, avoidance rows)")
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="one rank: run the step's RCCL exchange (a group of one) exactly as the N > 1 path issues it")
     args = ap.parse_args()
@@ -375,6 +412,8 @@ def main():
             out["rrt_connect"] = rrt_connect_gap_pass()
         if not args.no_edges and world == 1:
             out["edge_checks"] = edge_checks(dev)
+        if not args.no_distance and world == 1 and not sweep:
+            out["distance_path"] = distance_path(eng, w, d_soa, dev)
         print(json.dumps(out))
     eng.close()
     if exchange:
