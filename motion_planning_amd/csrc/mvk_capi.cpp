@@ -270,7 +270,7 @@ int boxes_to_obs(const mvk_box* boxes, size_t n, std::vector<DevObs>& host) {
 // the distance sought is known, the list holds every box that can realise the minimum and the sweep over all
 // boxes is not needed.  The slack is read off the scene: a percentile of the distance from a point of the
 // obstacles' bounding volume to the nearest box.  The full path bounds a state by its closest primitive and
-// takes the 70th percentile (short lists; a state needs the sweep only when the whole robot is farther than
+// takes the 60th percentile (short lists; a state needs the sweep only when the whole robot is farther than
 // that from every box); the avoidance rows need the nearest box of every primitive on its own and take the
 // 95th.  Measured on c2 / c2k / c3 / c5 (profiles/full_time.py with MVK_DISTANCE_GRID_PCT).  Scenes where the
 // lists would not be much shorter than the whole set keep the sweep (scalar loads at wave-uniform addresses).
@@ -316,7 +316,7 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
   }
   std::sort(dist.begin(), dist.end());
   for (int g = 0; g < 2; ++g) {
-    int pct = g == 0 ? 70 : 95;
+    int pct = g == 0 ? 60 : 95;
     if (const char* ov = std::getenv("MVK_DISTANCE_GRID_PCT")) if (std::atoi(ov) > 0 && std::atoi(ov) < 100) pct = std::atoi(ov);  // diagnostics
     double slack = std::fmin(std::fmax(dist[(kProbe * pct) / 100], 0.05), 4.0);
     GridHost gh;
