@@ -1,0 +1,13 @@
+#!/bin/bash
+# PMC passes over the distance kernels (profiles/full_time.py <workload>), summarised per kernel by summarize.py.
+# usage: bash profiles/pmc_full.sh <tag> <workload>
+TAG=$1; W=$2
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/pmcfull_${TAG}_$W
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM" "FETCH_SIZE" "GRBM_GUI_ACTIVE"; do
+  name=$(echo $pass | tr ' ' '_' | cut -c1-40)
+  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -o p -- python3 $ROOT/profiles/full_time.py $W > $OUT/pmc_$name.log 2>&1 || { echo "pass $pass failed"; tail -3 $OUT/pmc_$name.log; exit 1; }
+done
+python3 $ROOT/profiles/summarize.py $OUT
