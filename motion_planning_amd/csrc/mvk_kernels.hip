@@ -263,7 +263,7 @@ DEV double box_box_sat(const double t[3], const double R[9], const double a[3], 
       const double rb = fma(b[i1], Q[3 * i2 + j], b[i2] * Q[3 * i1 + j]);
       const double ra = fma(a[j1], Q[3 * i + j2], a[j2] * Q[3 * i + j1]);
       double g = fabs(fma(t[i2], R[3 * i1 + j], -t[i1] * R[3 * i2 + j])) - (ra + rb);
-      if (METRIC) g = g / sqrt(len2);
+      if (METRIC) g = g * rsqrt_nr(len2);  // 2 Newton steps: full precision up to rounding, a quarter of sqrt + divide
       g = (len2 < 1e-12) ? -INFINITY : g;  // parallel edges: axis degenerate, skip
       best = fmax(best, g);
     }
