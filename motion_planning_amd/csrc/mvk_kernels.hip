@@ -127,6 +127,15 @@ DEV double rsqrt_nr(double x) {
   return y;
 }
 
+// reciprocal by two Newton steps from v_rcp_f64: full precision up to rounding, a third of the IEEE divide.
+// x == 0 (or inf) gives NaN, which the callers' range tests discard like the +-inf of a true division.
+DEV double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(y, fma(-x, y, 1.0), y);
+  y = fma(y, fma(-x, y, 1.0), y);
+  return y;
+}
+
 // one Newton step: relative error ~1e-14, for scale factors of distances compared at 1e-5 / 1e-6
 DEV double rsqrt_nr1(double x) {
   const double y = __builtin_amdgcn_rsq(x);
@@ -203,7 +212,7 @@ DEV double seg_box_dist2(const double p0[3], const double d[3], const double h[3
   double tlo = 0.0, glo = g0, thi = 1.0, ghi = g1;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const double inv = 1.0 / d[k];
+    const double inv = rcp_nr(d[k]);  // NaN for d[k] == 0: no breakpoint on that axis, as with 1 / 0
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
       const double t = ((sg ? -h[k] : h[k]) - p0[k]) * inv;
@@ -310,7 +319,7 @@ DEV double seg_box_closest2(const double p0[3], const double d[3], const double 
   double tlo = 0.0, glo = g0, thi = 1.0, ghi = g1;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const double inv = 1.0 / d[k];
+    const double inv = rcp_nr(d[k]);  // NaN for d[k] == 0: no breakpoint on that axis, as with 1 / 0
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
       const double t = ((sg ? -h[k] : h[k]) - p0[k]) * inv;
