@@ -1167,14 +1167,15 @@ DEV double grid_upper_bound(const EvalArgs& A, bool on, const double pc[3]) {
 // grid_collect: `bound` is an upper bound of the distance sought.  Only boxes whose centre distance is at most
 // thr = rb + max(bound, 0) can undercut it (lower bound: centre distance - bounding radius); when thr is within
 // the grid's radius the cell's list holds all of them: they join the lane's candidate list, in ascending box
-// order, and the function returns true.  Otherwise (far from every box, outside the grid volume, beyond the
-// fp32 range: `on` false) nothing is listed.
-DEV bool grid_collect(const EvalArgs& A, const Smem& sm, bool on, const double pc[3], double rb, double bound, int& cnt) {
+// order, and the function returns true ([gb, ge): the cell's groups, for a lane whose candidates overflow its
+// list).  Otherwise (far from every box, outside the grid volume, beyond the fp32 range: `on` false) nothing is listed.
+DEV bool grid_collect(const EvalArgs& A, const Smem& sm, bool on, const double pc[3], double rb, double bound, int& cnt,
+                      unsigned& gb, unsigned& ge) {
   const int tid = threadIdx.x;
   const DevObsF* __restrict__ obsf = A.obsf;
   const double thr = rb + fmax(bound, 0.0);
+  gb = ge = 0;
   if (!(on && thr + 2.0 * static_cast<double>(A.f32_delta) <= A.dgrid_radius)) return false;
-  unsigned gb, ge;
   grid_cell(A.dgrid, pc, on, gb, ge);
   const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
   const float tf = (static_cast<float>(thr) + A.f32_delta) * 1.000001f;
@@ -1389,9 +1390,10 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       int cnt = 0;
       bool scan = live;  // lanes whose candidates come from the sweep over all boxes
       bool swept = false;
+      unsigned cell_b = 0, cell_e = 0;  // the grid cell's groups, when the candidates came from it
       if (use_grid) {
         const double bound = fmin(mind, upper);
-        if (grid_collect(A, sm, live && f32_safe, pc, rb, bound, cnt)) scan = false;
+        if (grid_collect(A, sm, live && f32_safe, pc, rb, bound, cnt, cell_b, cell_e)) scan = false;
         sweep_for_lanes_f32(A, sm, scan && f32_safe, pc, rb, bound, cnt);
         const bool slow = scan && !f32_safe;
         double b2 = INFINITY;
@@ -1432,9 +1434,15 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
         }
       }
       // -- narrowphase drain: kind is wave-uniform, list length is per lane ---
+      // a lane with more candidates than its list holds walks its grid cell's whole list instead (complete by
+      // construction), or every box of the scene when its candidates came from a sweep
       const bool overflow = cnt > kListCap;
-      int todo = live ? (overflow ? A.n_obs : cnt) : 0;
+      const bool from_cell = overflow && use_grid && !scan;
+      int todo = live ? (overflow ? (from_cell ? static_cast<int>(cell_e - cell_b) * kGridGroup : A.n_obs) : cnt) : 0;
       if (sphere && swept) todo = 0;
+      auto cand = [&](int e) -> int {  // kGridNone: padding, skip
+        return !overflow ? sm.list[e * kBlock + tid] : (from_cell ? A.dgrid.items[static_cast<size_t>(cell_b) * kGridGroup + e] : e);
+      };
 #ifdef MVK_PROF_COUNTS
       PROF_LANES(30, live); PROF_LANES(31, live && scan); PROF_LANES(32, live && overflow); PROF_SUM(33, live ? cnt : 0);
 #endif
@@ -1453,15 +1461,16 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
           double Rr[9], t[3], h[3];
 #pragma unroll 1
           while (e < todo && !need) {
-            // on overflow fall back to testing every obstacle for this primitive
-            const int ob = overflow ? e : sm.list[e * kBlock + tid];
-            const DevObs& O = obs[ob];
-            to_box_frame(O, pc, t);
-            box_rel(O, PR, Rr);
-            h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
-            const double g = box_box_sat<true>(t, Rr, a, h, mind);
-            if (g <= 0.0) mind = fmin(mind, g);
-            else need = g < mind;
+            const int ob = cand(e);
+            if (ob != kGridNone) {
+              const DevObs& O = obs[ob];
+              to_box_frame(O, pc, t);
+              box_rel(O, PR, Rr);
+              h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
+              const double g = box_box_sat<true>(t, Rr, a, h, mind);
+              if (g <= 0.0) mind = fmin(mind, g);
+              else need = g < mind;
+            }
             ++e;
           }
           // the exact distances, kExactBatch pairs at a time over the whole wave: the pairs go to LDS and every
@@ -1525,8 +1534,8 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       } else {
 #pragma unroll 1
         for (int e = 0; __any(e < todo); ++e) {
-          if (e < todo) {
-            const int ob = overflow ? e : sm.list[e * kBlock + tid];
+          const int ob = e < todo ? cand(e) : kGridNone;
+          if (ob != kGridNone) {
             const DevObs O = obs[ob];
             double t[3];
             to_box_frame(O, pc, t);
@@ -2270,9 +2279,12 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
       PROF_T0(t_c);
       int cnt = 0;
+      unsigned cell_b = 0, cell_e = 0;
+      bool from_grid = false;
       if (use_grid) {
         bool scan = in_range;
-        if (grid_collect(A, sm, in_range && f32_safe, pc, rb, grid_upper_bound(A, in_range && f32_safe, pc), cnt)) scan = false;
+        if (grid_collect(A, sm, in_range && f32_safe, pc, rb, grid_upper_bound(A, in_range && f32_safe, pc), cnt, cell_b, cell_e)) scan = false;
+        from_grid = !scan;
         double b2 = INFINITY;
         int c2 = 0;
         sweep_for_lanes_f32(A, sm, scan && f32_safe, pc, rb, INFINITY, cnt);
@@ -2302,8 +2314,12 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
           }
         }
       }
-      const bool overflow = cnt > kListCap;
-      const int todo = (use_grid && !in_range) ? 0 : (overflow ? A.n_obs : cnt);
+      const bool overflow = cnt > kListCap;   // as in the full kernel: the cell's whole list, or every box
+      const bool from_cell = overflow && from_grid && in_range;
+      const int todo = (use_grid && !in_range) ? 0 : (overflow ? (from_cell ? static_cast<int>(cell_e - cell_b) * kGridGroup : A.n_obs) : cnt);
+      auto cand = [&](int e) -> int {  // kGridNone: padding, skip
+        return !overflow ? sm.list[e * kBlock + tid] : (from_cell ? A.dgrid.items[static_cast<size_t>(cell_b) * kGridGroup + e] : e);
+      };
       PROF_CLK(0, t_c);
       PROF_T0(t_d);
 #ifdef MVK_PROF_COUNTS
@@ -2336,8 +2352,8 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
         PROF_T0(t_a);
 #pragma unroll 1
         for (int e = 0; __any(e < todo); ++e) {
-          if (e < todo) {
-            const int ob = overflow ? e : sm.list[e * kBlock + tid];
+          const int ob = e < todo ? cand(e) : kGridNone;
+          if (ob != kGridNone) {
             const DevObs& O = obs[ob];
             double Rr[9], t[3];
             to_box_frame(O, pc, t);
@@ -2353,7 +2369,7 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
           const bool first = emin >= 0 && gmin <= best;
           if (__any(first)) {
             if (first) {
-              const int ob = overflow ? emin : sm.list[emin * kBlock + tid];
+              const int ob = cand(emin);
               const DevObs O = obs[ob];
               double Rr[9], t[3], pr[3], pq[3];
               to_box_frame(O, pc, t);
@@ -2372,8 +2388,8 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
           double Rr[9], t[3];
 #pragma unroll 1
           while (e < todo && !need) {
-            if (e != emin) {
-              const int ob = overflow ? e : sm.list[e * kBlock + tid];
+            const int ob = e != emin ? cand(e) : kGridNone;
+            if (ob != kGridNone) {
               const DevObs& O = obs[ob];
               to_box_frame(O, pc, t);
               box_rel(O, PR, Rr);
@@ -2471,8 +2487,8 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       } else {
 #pragma unroll 1
         for (int e = 0; __any(e < todo); ++e) {
-          if (e < todo) {
-            const int ob = overflow ? e : sm.list[e * kBlock + tid];
+          const int ob = e < todo ? cand(e) : kGridNone;
+          if (ob != kGridNone) {
             const DevObs O = obs[ob];
             double t[3], pr[3], pq[3];
             to_box_frame(O, pc, t);

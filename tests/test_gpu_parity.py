@@ -101,9 +101,10 @@ def test_distance_grid_and_sweep_give_identical_distances(monkeypatch):
         assert np.array_equal(out[0]["flags"], out[1]["flags"]) and np.array_equal(out[0]["band"], out[1]["band"])
 
 
-def test_candidate_list_overflow_falls_back_to_every_box():
-    """more boxes near one primitive than a lane's candidate list holds (32): the lane then tests every box of the
-    scene for that primitive -- distances, flags and the avoidance rows' nearest box still match the oracle"""
+def test_candidate_list_overflow_falls_back_to_every_box(monkeypatch):
+    """more boxes near one primitive than a lane's candidate list holds (32): the lane then walks its grid cell's whole
+    list (or every box of the scene, without the grid) for that primitive -- distances, flags and the avoidance rows'
+    nearest box still match the oracle, and the two fallbacks agree bit for bit"""
     rng = np.random.default_rng(77)
     w = common.config2k(n=1500)
     cluster = common.random_boxes(rng, 120, [0.8, -0.4, -0.3], [1.6, 0.4, 0.3], 0.01, 0.03, "so3")   # a swarm of small boxes
@@ -121,6 +122,18 @@ def test_candidate_list_overflow_falls_back_to_every_box():
     assert np.allclose(got["dist"], ref["dist"], rtol=1e-5, atol=1e-9)
     tie = np.abs(got["dist"] - ref["dist"]) > 0
     assert np.all((got["box"] == ref["box"]) | tie) and np.array_equal(got["ok"], ref["ok"])
+    monkeypatch.setenv("MVK_NO_DISTANCE_GRID", "1")
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    plain = eng.collision_avoidance_batch(w.soa[:, :400], w.layout)
+    plain_full = eng.eval_batch(w.soa, w.layout)
+    eng.close()
+    monkeypatch.setenv("MVK_NO_DISTANCE_GRID", "0")
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    grid_full = eng.eval_batch(w.soa, w.layout)
+    eng.close()
+    assert np.array_equal(plain["dist"], got["dist"]) and np.array_equal(plain["box"], got["box"])
+    assert np.array_equal(plain["row"], got["row"], equal_nan=True)
+    assert np.array_equal(plain_full["min_dist"], grid_full["min_dist"])
 
 
 def test_c3_dragon4_vs_oracle():
