@@ -88,7 +88,20 @@ def test_distance_grid_lanes_mixed_with_sweep_lanes():
 def test_distance_grid_and_sweep_give_identical_distances(monkeypatch):
     """the grid only changes WHICH pairs reach the fp64 narrowphase, never the value of the closest one: at a
     size the oracle does not reach, the distances with and without it are the same bits"""
-    for make, n in ((common.config2k, 150000), (common.config3, 100000), (common.config5, 100000)):
+    def walls(n):      # long thin walls and slabs: bounding spheres far larger than the boxes
+        w = common.config2k(n=n)
+        rng = np.random.default_rng(9)
+        w.boxes = common.random_boxes(rng, 400, [-2.0, -2.2, -2.2], [5.0, 2.2, 2.2], 0.02, 0.05, "so3")
+        w.boxes[:, 7 + rng.integers(0, 3, 400)[0]] = 2.0   # one common long side ...
+        w.boxes[np.arange(400), 7 + rng.integers(0, 3, 400)] = rng.uniform(1.0, 3.0, 400)   # ... and one per box
+        return w
+
+    def pebbles(n):    # thousands of tiny boxes
+        w = common.config3(n=n)
+        w.boxes = common.random_boxes(np.random.default_rng(10), 5000, [-2.0] * 3, [2.0, 2.0, 2.5], 0.005, 0.03, "so3")
+        return w
+
+    for make, n in ((common.config2k, 150000), (common.config3, 100000), (common.config5, 100000), (walls, 60000), (pebbles, 60000)):
         w = make(n=n)
         w.soa[0, 0::17] += 2.5   # a share of lanes the grid cannot answer in every wave
         out = []
@@ -99,6 +112,17 @@ def test_distance_grid_and_sweep_give_identical_distances(monkeypatch):
             eng.close()
         assert np.array_equal(out[0]["min_dist"], out[1]["min_dist"]), w.name
         assert np.array_equal(out[0]["flags"], out[1]["flags"]) and np.array_equal(out[0]["band"], out[1]["band"])
+        # the avoidance rows' per-primitive nearest box, distance and points as well
+        av = []
+        for off in ("0", "1"):
+            monkeypatch.setenv("MVK_NO_DISTANCE_GRID", off)
+            eng = mp.Engine(w.model, w.boxes, w.params)
+            av.append(eng.collision_avoidance_batch(w.soa[:, :20000], w.layout))
+            eng.close()
+        for k in ("dist", "box", "ok", "lb"):
+            assert np.array_equal(av[0][k], av[1][k]), (w.name, k)
+        for k in ("p_env", "p_robot", "row"):
+            assert np.array_equal(av[0][k], av[1][k], equal_nan=True), (w.name, k)
 
 
 def test_candidate_list_overflow_falls_back_to_every_box(monkeypatch):
