@@ -85,23 +85,36 @@ def test_distance_grid_lanes_mixed_with_sweep_lanes():
     print("c2k clustered:", r)
 
 
+def _walls(n):      # long thin walls and slabs: bounding spheres far larger than the boxes
+    w = common.config2k(n=n)
+    rng = np.random.default_rng(9)
+    w.boxes = common.random_boxes(rng, 400, [-2.0, -2.2, -2.2], [5.0, 2.2, 2.2], 0.02, 0.05, "so3")
+    w.boxes[np.arange(400), 7 + rng.integers(0, 3, 400)] = rng.uniform(1.0, 3.0, 400)   # one long side per box
+    w.name = "walls"
+    return w
+
+
+def _pebbles(n):    # thousands of tiny boxes
+    w = common.config3(n=n)
+    w.boxes = common.random_boxes(np.random.default_rng(10), 5000, [-2.0] * 3, [2.0, 2.0, 2.5], 0.005, 0.03, "so3")
+    w.name = "pebbles"
+    return w
+
+
+def test_walls_and_pebbles_vs_oracle():
+    """scenes unlike the benchmark ones: boxes whose bounding spheres are far larger than they are (fp32 screen
+    thresholds, grid cell bounds), and thousands of boxes smaller than any robot primitive"""
+    r = check_against_oracle(_walls(2500), 2500)
+    print("walls:", r)
+    assert 0.02 < r["valid"] / r["n"] < 0.98
+    r = check_against_oracle(_pebbles(1200), 1200)
+    print("pebbles:", r)
+
+
 def test_distance_grid_and_sweep_give_identical_distances(monkeypatch):
     """the grid only changes WHICH pairs reach the fp64 narrowphase, never the value of the closest one: at a
     size the oracle does not reach, the distances with and without it are the same bits"""
-    def walls(n):      # long thin walls and slabs: bounding spheres far larger than the boxes
-        w = common.config2k(n=n)
-        rng = np.random.default_rng(9)
-        w.boxes = common.random_boxes(rng, 400, [-2.0, -2.2, -2.2], [5.0, 2.2, 2.2], 0.02, 0.05, "so3")
-        w.boxes[:, 7 + rng.integers(0, 3, 400)[0]] = 2.0   # one common long side ...
-        w.boxes[np.arange(400), 7 + rng.integers(0, 3, 400)] = rng.uniform(1.0, 3.0, 400)   # ... and one per box
-        return w
-
-    def pebbles(n):    # thousands of tiny boxes
-        w = common.config3(n=n)
-        w.boxes = common.random_boxes(np.random.default_rng(10), 5000, [-2.0] * 3, [2.0, 2.0, 2.5], 0.005, 0.03, "so3")
-        return w
-
-    for make, n in ((common.config2k, 150000), (common.config3, 100000), (common.config5, 100000), (walls, 60000), (pebbles, 60000)):
+    for make, n in ((common.config2k, 150000), (common.config3, 100000), (common.config5, 100000), (_walls, 60000), (_pebbles, 60000)):
         w = make(n=n)
         w.soa[0, 0::17] += 2.5   # a share of lanes the grid cannot answer in every wave
         out = []
