@@ -8,8 +8,12 @@
 // shared out over the wave through an LDS ring; the states it cannot decide are
 // handed (state index + a compact record) to exact_kernel, which runs the fp64
 // narrowphase one (primitive, box) pair per lane.  Wave-uniform data (model
-// constants) comes through scalar loads; the full / avoidance kernels are the
-// all-boxes correctness path with per-lane LDS candidate lists.  DESIGN.md 4-5.
+// constants) comes through scalar loads.  The distance kernels (full_kernel:
+// exact minimum distance, margins, statistics; avoid_kernel: nearest box and
+// points per primitive) take per-lane candidate lists from distance grids keyed
+// by primitive centres, serve the lanes a grid cannot answer with a
+// wave-cooperative sweep over all boxes, and compute the expensive exact
+// box-box distances as (pair, edge) items over the whole wave.  DESIGN.md 4-5.
 //
 // What one state evaluation computes (V-spec), replacing
 //   MotionPlanning::isStateValid            sampling_based_method/src/motion_planning.cpp:76-164
