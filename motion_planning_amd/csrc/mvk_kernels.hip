@@ -437,7 +437,10 @@ struct Smem {
   // edge index among each pair's minima, [kCpBatch]
   lds_double* ex_s2;
   lds_uint* ex_win;
+  // full path: per primitive (first kUpperSlots of the chain order) the first walk's upper bound, [kUpperSlots][kBlock]
+  lds_float* upper;
 };
+constexpr int kUpperSlots = 16;
 constexpr int kExactBatch = 16;  // box pairs whose exact distance one wave computes together
 constexpr int kCpBatch = 8;      // the same for the avoidance rows (closest points as well)
 constexpr int kExactItem = 16;   // doubles per pair: relative rotation 9, centre 3, box half extents 3, pad
@@ -1367,7 +1370,9 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       for (int qi = pb; qi < pe; ++qi) {
         double pc[3];
         prim_pose<S::kGimbal, false>(M, X->prim_order[qi], R, p, pc, nullptr);
-        upper = fmin(upper, grid_upper_bound(A, live && f32_safe, pc));
+        const double up = grid_upper_bound(A, live && f32_safe, pc);
+        if (qi < kUpperSlots) sm.upper[qi * kBlock + tid] = static_cast<float>(up) * 0.999999f;  // rounded down
+        upper = fmin(upper, up);
       }
     }
 #pragma unroll
@@ -1397,7 +1402,15 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       unsigned cell_b = 0, cell_e = 0;  // the grid cell's groups, when the candidates came from it
       if (use_grid) {
         const double bound = fmin(mind, upper);
-        if (grid_collect(A, sm, live && f32_safe, pc, rb, bound, cnt, cell_b, cell_e)) scan = false;
+        // the first walk's minimum for this primitive: when even its nearest listed box is too far to undercut
+        // the bound (lower bound: centre distance - bounding radius), and the list is complete for that threshold,
+        // there is nothing to collect -- most primitives of a state, since only the few nearest matter
+        const double dd = 2.0 * static_cast<double>(A.f32_delta);
+        const double thr0 = rb + fmax(bound, 0.0);
+        const bool none = qi < kUpperSlots && live && f32_safe && thr0 + dd <= A.dgrid_radius &&
+                          static_cast<double>(sm.upper[qi * kBlock + tid]) - dd > thr0 + dd;
+        if (none) scan = false;
+        else if (grid_collect(A, sm, live && f32_safe, pc, rb, bound, cnt, cell_b, cell_e)) scan = false;
         sweep_for_lanes_f32(A, sm, scan && f32_safe, pc, rb, bound, cnt);
         const bool slow = scan && !f32_safe;
         double b2 = INFINITY;
@@ -2119,8 +2132,9 @@ full_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* 
   __shared__ unsigned short sm_list[kListCap * kBlock];
   __shared__ double sm_ex_item[(kBlock / 64) * kExactBatch * kExactItem];
   __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kExactBatch];
+  __shared__ float sm_upper[kUpperSlots * kBlock];
   Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list, (lds_double*)sm_ex_item + (threadIdx.x >> 6) * kExactBatch * kExactItem,
-          (lds_u64*)sm_ex_res + (threadIdx.x >> 6) * kExactBatch};
+          (lds_u64*)sm_ex_res + (threadIdx.x >> 6) * kExactBatch, nullptr, nullptr, (lds_float*)sm_upper};
 
   const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool in_range = gi < A.n;
