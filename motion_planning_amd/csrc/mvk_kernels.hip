@@ -1203,6 +1203,43 @@ DEV bool grid_collect(const EvalArgs& A, const Smem& sm, bool on, const double p
   return true;
 }
 
+// grid_collect_nearest: both steps in one pass over the cell's list, for the avoidance rows (no bound is known
+// beforehand there: the primitive's own nearest box sets it).  The threshold follows the running minimum, so the
+// list also keeps a few boxes met before the nearest one -- the drain's separating-axis gaps discard them.
+DEV bool grid_collect_nearest(const EvalArgs& A, const Smem& sm, bool on, const double pc[3], double rb, int& cnt, unsigned& gb, unsigned& ge) {
+  const int tid = threadIdx.x;
+  const DevObsF* __restrict__ obsf = A.obsf;
+  grid_cell(A.dgrid, pc, on, gb, ge);
+  const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
+  const float rbf = static_cast<float>(rb) * 1.000001f + 2.0f * A.f32_delta;
+  float best2f = INFINITY, thr2f = INFINITY;
+  int n = 0;
+#pragma unroll 1
+  for (unsigned g = gb; g < ge; ++g) {
+    const ushort4 v = *reinterpret_cast<const ushort4*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
+    const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < kGridGroup; ++e) {
+      const float l2 = point_box_dist2_f32(obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]], x, y, z);
+      if (ids[e] != kGridNone) {
+        if (l2 < best2f) {
+          best2f = l2;
+          const float t = (rbf + sqrtf(l2) * 1.000001f) * 1.000001f;
+          thr2f = t * t;
+        }
+        if (l2 <= thr2f) {
+          if (n < kListCap) sm.list[n * kBlock + tid] = ids[e];
+          ++n;
+        }
+      }
+    }
+  }
+  const double up = static_cast<double>(sqrtf(best2f)) * 1.000001 + static_cast<double>(A.f32_delta);
+  if (!(on && rb + up + 2.0 * static_cast<double>(A.f32_delta) <= A.dgrid_radius)) return false;
+  cnt = n;
+  return true;
+}
+
 // The sweep over all boxes for the lanes the grid could not answer (`scan`; typically primitives that stick out
 // of the obstacles' volume), in fp32 and by the whole wave: every lane holds one box per round and tests it for
 // each such lane in turn (centre broadcast from that lane), so a box is loaded once per round however many lanes
@@ -2301,7 +2338,7 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       bool from_grid = false;
       if (use_grid) {
         bool scan = in_range;
-        if (grid_collect(A, sm, in_range && f32_safe, pc, rb, grid_upper_bound(A, in_range && f32_safe, pc), cnt, cell_b, cell_e)) scan = false;
+        if (grid_collect_nearest(A, sm, in_range && f32_safe, pc, rb, cnt, cell_b, cell_e)) scan = false;
         from_grid = !scan;
         double b2 = INFINITY;
         int c2 = 0;
