@@ -66,7 +66,7 @@ struct PinBuf {  // grow-only pinned host buffer (async copies from pageable mem
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
-    size_t want = bytes + bytes / 4 + 4096;
+    size_t want = std::max<size_t>(bytes + bytes / 4 + 4096, size_t{1} << 18);  // small calls never re-pin
     HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
     cap = want;
     return MVK_OK;
