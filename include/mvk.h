@@ -138,7 +138,10 @@ typedef struct mvk_params {
   double pos_low[3], pos_high[3]; /* motion_planning.cpp:471-476 */
   double joint_low[MVK_MAX_JOINT], joint_high[MVK_MAX_JOINT]; /* :478-484 */
   double validity_resolution;        /* state_validity_check_res, :527 (0.03) */
-  int32_t valid_segment_count_factor; /* :528 (20) */
+  /* :528 (20).  Counts in mode 0 only: in mode 1 the reference sets it on the SE2/SE3
+   * compound space (:244), which never reads it (the reference's mode-1 log
+   * path_log/hydrus/planning_log.txt has ceil(d / (extent * res)) states per edge). */
+  int32_t valid_segment_count_factor;
   /* Quirk Q4 (motion_planning.cpp:252-258): mode 2 never installs resolution /
    * factor, so OMPL defaults (0.01, 1) apply.  1 = reproduce that. */
   int32_t mode2_ompl_defaults;

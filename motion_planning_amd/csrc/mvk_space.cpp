@@ -120,9 +120,13 @@ extern "C" double mvk_space_max_extent(const mvk_params* p, int J) {
   return combine(p, t.extent, r.extent, j.extent);
 }
 
-// validSegmentCount: every leaf space counts factor * ceil(d / (extent * fraction));
-// compound spaces keep the maximum.  Mode 2 is never given a resolution or a
-// factor by the reference (quirk Q4) and so runs on OMPL's defaults 1 % / 1.
+// validSegmentCount: a leaf space counts factor * ceil(d / (extent * fraction)); a compound space keeps the
+// maximum over its leaves and never reads a factor of its own.  The reference sets the factor on config_space_
+// itself (motion_planning.cpp:233,244): in mode 0 that is the RealVector leaf, so the factor counts; in mode 1 it
+// is the SE2/SE3 compound, whose leaves keep factor 1, while setStateValidityCheckingResolution (:237,248) does
+// reach the leaves (quirk Q13, pinned by the reference's mode-1 log path_log/hydrus/planning_log.txt: its edges
+// have ceil(d / (extent * 0.005)) states, not 20 times that).  Mode 2 is never given a resolution or a factor
+// (quirk Q4) and so runs on OMPL's defaults 1 % / 1.
 extern "C" int mvk_space_valid_segment_count(const mvk_params* p, int J, const double* s1,
                                              const double* s2) {
   double fraction = p->validity_resolution;
@@ -131,6 +135,7 @@ extern "C" int mvk_space_valid_segment_count(const mvk_params* p, int J, const d
     fraction = 0.01;
     factor = 1;
   }
+  if (p->planning_mode == MVK_MODE_ONLY_BASE) factor = 1;  // quirk Q13
   Leaf leaf[3];
   measure(p, J, s1, s2, leaf[0], leaf[1], leaf[2]);
   int count = 0;

@@ -813,11 +813,15 @@ double orc_space_max_extent(const mvk_params* p, int J) {
 /* StateSpace::validSegmentCount = factor * ceil(distance / (maxExtent * fraction))
  * per leaf; a compound takes the max over its components.  In mode 2 the
  * reference installs neither resolution nor factor (quirk Q4), so OMPL's
- * defaults 0.01 / 1 apply when mode2_ompl_defaults is set. */
+ * defaults 0.01 / 1 apply when mode2_ompl_defaults is set.  In mode 1 the
+ * reference sets the factor on the SE2/SE3 compound (motion_planning.cpp:244),
+ * which never reads it, while the resolution (:248) reaches the leaves: pinned
+ * by path_log/hydrus/planning_log.txt (tests/test_pathlog_pin_more.py). */
 int orc_space_valid_segment_count(const mvk_params* p, int J, const double* a, const double* b) {
   double frac = p->validity_resolution;
   int factor = p->valid_segment_count_factor;
   if (p->planning_mode == MVK_MODE_JOINTS_AND_BASE && p->mode2_ompl_defaults) { frac = 0.01; factor = 1; }
+  if (p->planning_mode == MVK_MODE_ONLY_BASE) factor = 1;
   leaf_info L[3]; int pr[3];
   leaves(p, J, a, b, L, pr);
   int best = 0;

@@ -1,0 +1,161 @@
+"""PIN: more of the reference's own planner logs, used as data (tests/golden/ref_*.txt are verbatim copies of
+files under aerial_motion/sampling_based_method/path_log/).
+
+* ref_dragon_log_gap_0p5_wall3_best.txt  (path_log/dragon/dragon_planning_log_new_vertial_gap_0p5_ceil_1p4_with_side_wall3_best.txt.orig,
+  the planner's unedited output) and ref_dragon_log_gap_0p6_wall3_best.txt (…0p6…wall3_best.txt): mode 2 / SE(3), 366 and
+  256 states of 21 values = pose 7 + 6 link joints + 8 gimbal angles (roll, pitch per link).  The gimbal angles are the
+  outputs of Dragon::HydrusLikeRobotModel::getGimbalProcessedJoint (absent third-party code; call site
+  multilink_state.cpp:81,136): they pin the joint convention of the DRAGON chain (pitch about y, then yaw about z,
+  per inter-link joint) and the gimbal solve of row a3.  The states also split into 13 + 8 edges at the doubled
+  way-points (motion_planning.cpp:424-446), which pins validSegmentCount and interpolate of the SE(3) x R^6
+  compound space (slerp, OMPL defaults in mode 2, bounds of the logs' *_param3.txt companions = dragon_quad.yaml:37-46).
+* ref_dragon_log_tilt_45deg_gap_0p8.txt (…tilt_45deg_gap_0p8.txt): an older revision (13 values + 2 trailers per state,
+  unknown bounds): pins the slerp interpolation only (the rotation changes by up to 180 degrees here).
+* ref_hydrus_planning_log_mode1.txt (path_log/hydrus/planning_log.txt): mode 1 / SE(2), 390 states: pins the
+  (resolution, factor) branch of motion_planning.cpp:244-249 -- the edges have ceil(d / (maxExtent * 0.005)) states: the
+  launch files' resolution 0.005 reaches the leaves, the factor 20 set on the compound space does not (quirk Q13).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import motion_planning_amd as mp
+import oracle_lib as O
+from motion_planning_amd import _abi as A
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DRAGON_LOGS = ("ref_dragon_log_gap_0p5_wall3_best.txt", "ref_dragon_log_gap_0p6_wall3_best.txt")
+
+
+def load_states(name):
+    rows = []
+    for line in open(os.path.join(GOLD, name)):
+        if line.startswith("state") and not line.startswith("states"):
+            rows.append([float(x) for x in line.split()[1:]])
+    return np.array(rows)
+
+
+def edges_of(S):
+    """way-points are logged twice in a row (addState(state2), then addState(state1) of the next pair)"""
+    dup = [i for i in range(1, len(S)) if np.array_equal(S[i], S[i - 1])]
+    out, start = [], 0
+    for d in dup + [len(S)]:
+        out.append((start, d - 1))
+        start = d
+    return [(a, b) for a, b in out if b > a]
+
+
+def print_tol(ref):
+    """the logs print 6 significant digits: half a unit of the last digit on the state itself plus as much again
+    carried over from the printed end points it is interpolated from"""
+    return 1e-5 * np.maximum(1.0, np.abs(ref)) + 3e-6
+
+
+def dragon_space(which):
+    m = mp.make_model("dragon", 4)
+    p = mp.default_params(m, A.MODE_JOINTS_AND_BASE, A.SE3)
+    p.pos_low[:] = [-1.0, -1.0, 0.0]     # x/y/z_low_bound of the logs' *_param3.txt (= dragon_quad.yaml:37-42)
+    p.pos_high[:] = [1.0, 1.0, 1.4]
+    return (mp.Space if which == "product" else O.Space)(p, m.n_joint)
+
+
+def check_interior(sp, S, a, b):
+    n = b - a
+    for j in range(1, n):
+        got = sp.interpolate(S[a], S[b], j / n)
+        ref = S[a + j]
+        if np.dot(got[3:7], ref[3:7]) < 0:
+            got[3:7] = -got[3:7]
+        assert np.all(np.abs(got - ref) <= print_tol(ref)), (a, b, j, got, ref)
+
+
+@pytest.mark.parametrize("log", DRAGON_LOGS)
+def test_oracle_gimbal_angles_match_the_logged_ones(log):
+    S = load_states(log)
+    assert S.shape[1] == 21
+    m = mp.make_model("dragon", 4)
+    p = mp.default_params(m, A.MODE_JOINTS_AND_BASE, A.SE3)
+    out = O.eval_batch(m, np.zeros((0, 10)), p, np.ascontiguousarray(S[:, :13].T), A.LAYOUT_POSE7)
+    err = np.abs(out["gimbal"].T - S[:, 13:21])
+    # 13 inputs printed to 6 digits (absolute error <= 8e-6 each, unit sensitivity) + the printed output
+    assert err.max() < 6e-5, err.max()
+    assert np.median(err) < 2e-6
+    # a different joint convention is far outside that: yaw before pitch moves the angles by ~1e-1
+    assert np.abs(S[:, 13:21]).max() > 0.5
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+@pytest.mark.parametrize("log,counts", [(DRAGON_LOGS[0], [22, 32, 25, 22, 42, 19, 20, 32, 25, 33, 33, 27, 21]),
+                                        (DRAGON_LOGS[1], [24, 44, 33, 28, 36, 39, 25, 19])])
+def test_se3_segment_counts_and_slerp_match_the_dragon_logs(which, log, counts):
+    sp = dragon_space(which)
+    S = load_states(log)[:, :13]
+    E = edges_of(S)
+    assert [b - a for a, b in E] == counts
+    for a, b in E:
+        assert sp.valid_segment_count(S[a], S[b]) == b - a, (a, b)
+        check_interior(sp, S, a, b)
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+def test_slerp_matches_the_tilted_gap_log(which):
+    sp = dragon_space(which)
+    S = load_states("ref_dragon_log_tilt_45deg_gap_0p8.txt")[:, :13]
+    E = edges_of(S)
+    assert [b - a for a, b in E] == [47, 28, 42, 53, 1]
+    turned = 0.0
+    for a, b in E:
+        check_interior(sp, S, a, b)
+        turned = max(turned, 2.0 * math.acos(min(1.0, abs(float(np.dot(S[a, 3:7], S[b, 3:7]))))))
+    assert turned > 1.0    # the edges really rotate (up to 180 degrees between start and goal)
+
+
+def mode1_ompl(row):
+    yaw = 2.0 * math.atan2(row[5], row[6])
+    return np.array([row[0], row[1], (yaw + math.pi) % (2 * math.pi) - math.pi])
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+def test_mode1_log_pins_the_resolution_branch(which):
+    m = mp.make_model("hydrus", 4)
+    p = mp.default_params(m, A.MODE_ONLY_BASE, A.SE2)
+    assert (p.validity_resolution, p.valid_segment_count_factor) == (0.03, 20)   # motion_planning.cpp:527-528
+    p.validity_resolution = 0.005   # the launch files' value (gap_passing_planning.launch:44)
+    sp = (mp.Space if which == "product" else O.Space)(p, m.n_joint)
+    S = load_states("ref_hydrus_planning_log_mode1.txt")
+    assert S.shape == (390, 10)
+    E = edges_of(S)
+    assert [b - a for a, b in E] == [120, 20, 16, 42, 187]
+    for a, b in E:
+        s1, s2 = mode1_ompl(S[a]), mode1_ompl(S[b])
+        assert sp.valid_segment_count(s1, s2) == b - a     # factor 20 is NOT applied (quirk Q13)
+        for j in range(1, b - a):
+            got = sp.unpack(sp.interpolate(s1, s2, j / (b - a)))
+            ref = S[a + j].copy()
+            ref[7:] = 0.0      # quirk Q3: mode 1 evaluates with zero joints; the log carries the start state's
+            if np.dot(got[3:7], ref[3:7]) < 0:
+                got[3:7] = -got[3:7]
+            assert np.all(np.abs(got - ref) <= print_tol(ref)), (a, b, j, got, ref)
+    # mode 0 is the one space whose factor counts (RealVector leaf: motion_planning.cpp:233)
+    p0 = mp.default_params(m, A.MODE_ONLY_JOINTS, A.SE2)
+    s0 = (mp.Space if which == "product" else O.Space)(p0, m.n_joint)
+    a, b = np.array([0.0, 0.0, 0.0]), np.array([0.3, 0.0, 0.0])
+    ext = math.sqrt(3 * 3.16 ** 2)
+    assert s0.valid_segment_count(a, b) == 20 * math.ceil(0.3 / (ext * 0.03))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log", DRAGON_LOGS)
+def test_gpu_gimbal_angles_match_the_logged_ones(log):
+    """product: mvk_eval_batch detail.gimbal (model_update of the full kernel) on the logged states"""
+    S = load_states(log)
+    m = mp.make_model("dragon", 4)
+    p = mp.default_params(m, A.MODE_JOINTS_AND_BASE, A.SE3)
+    eng = mp.Engine(m, mp.vertical_gap_scene(0.5, 0.5, 0.7), p)
+    got = eng.eval_batch(np.ascontiguousarray(S[:, :13].T), A.LAYOUT_POSE7)
+    eng.close()
+    err = np.abs(got["gimbal"].T - S[:, 13:21])
+    assert err.max() < 6e-5, err.max()
+    assert np.median(err) < 2e-6
