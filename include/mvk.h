@@ -13,7 +13,12 @@
  *     (ld >= n is the row pitch in elements), so a wavefront reads 64
  *     consecutive doubles per row (coalesced 512 B).
  *   - "host" entry points take host pointers and copy; "_dev" entry points take
- *     device pointers (HBM resident) plus a hipStream_t passed as void*.
+ *     device pointers (HBM resident) plus a hipStream_t passed as void*: the work
+ *     is enqueued on that stream and the call returns without synchronising.
+ *   - calls on one ctx share its scratch buffers, so the library keeps them in
+ *     issue order on the device: a _dev call on another stream than the ctx's
+ *     previous call first makes its stream wait (hipStreamWaitEvent) for that
+ *     call's work.  A ctx is still for one host thread at a time.
  *   - there is NO CPU fallback: every compute entry point fails with
  *     MVK_ERR_NO_DEVICE when no gfx950 device / HIP runtime is usable.
  */
@@ -244,7 +249,12 @@ int mvk_state_dim(const mvk_ctx* ctx, int layout);
 
 /* ---- the predicate --------------------------------------------------------- */
 /* MotionPlanning::isStateValid (motion_planning.cpp:76-164) for ONE state in
- * MVK_LAYOUT_OMPL.  Runs the same device kernel on a batch of one. */
+ * MVK_LAYOUT_OMPL.  Runs the same device kernel on a batch of one.
+ * MotionPlanning::checkCollision(const MultilinkState&) (motion_planning.cpp:802-810:
+ * collision of an arbitrary state, no stability test, whatever the planning mode) is
+ * this call on a ctx whose params have check_stability = 0, check_collision = 1, read
+ * through out->collision.  The reference's version always returns true and only warns
+ * (quirk Q8); that is not reproduced.  tests/test_gate_overrides.py covers both. */
 int mvk_is_valid(mvk_ctx* ctx, const double* state, mvk_result* out);
 
 /* Batched predicate (north star: isValid(states[N])).  flags[i] = 1 valid.

@@ -4,25 +4,33 @@
 // (sampling_based_method/src/motion_planning.cpp):
 //   :236,:247,:257  si->setStateValidityChecker(boost::bind(&MotionPlanning::isStateValid, this, _1))
 //   :238,:249       si->setMotionValidator(MotionValidatorPtr(new DiscreteMotionValidator(si)))
-// with the same virtual signatures
+// as classes derived from ompl::base::StateValidityChecker / ompl::base::MotionValidator, overriding
 //   bool isValid(const ompl::base::State*) const
 //   bool checkMotion(const State* s1, const State* s2) const
 //   bool checkMotion(const State* s1, const State* s2, std::pair<State*, double>& lastValid) const
-// plus the batched entry point the north star adds:
+// plus the batched entry points the north star adds:
 //   void isValid(const State* const* states, std::size_t n, std::uint8_t* out) const
+//   void checkMotions(const State* const* from, const State* const* to, std::size_t n, ok, first_invalid) const
 //
-// The header is written against the OMPL class names.  OMPL is not installed in
-// the build image, so when MVK_OMPL_STUB is defined a minimal look-alike of the
-// handful of OMPL types that are touched is provided (same member names as
-// ompl::base::{State, CompoundState, SE2StateSpace::StateType,
-// SE3StateSpace::StateType, SO3StateSpace::StateType,
-// RealVectorStateSpace::StateType}); with real OMPL simply include the OMPL
-// headers first and leave MVK_OMPL_STUB undefined.
+// The header is written against the OMPL class names.  OMPL is not installed in the build image, so when
+// MVK_OMPL_STUB is defined a minimal look-alike of the handful of OMPL types that are touched is provided (same
+// member names as ompl::base::{State, CompoundState, SE2StateSpace::StateType, SE3StateSpace::StateType,
+// SO3StateSpace::StateType, RealVectorStateSpace::StateType, SpaceInformationPtr, StateValidityChecker,
+// MotionValidator}); the adapter classes below are ONE body of code for both cases.  With real OMPL include
+//   <ompl/base/SpaceInformation.h> <ompl/base/StateValidityChecker.h> <ompl/base/MotionValidator.h>
+//   <ompl/base/spaces/SE2StateSpace.h> <ompl/base/spaces/SE3StateSpace.h> <ompl/base/spaces/RealVectorStateSpace.h>
+// first and leave MVK_OMPL_STUB undefined.  (That build has never been compiled here -- OMPL is absent from the
+// image; the stub build is compiled and RUN by tests/test_gpu_adapter.py through csrc/mvk_adapter_check.cpp.)
+//
+// Errors: OMPL's planner loops do not expect exceptions from a validity checker, so a failing C-ABI call makes
+// the state / motion INVALID (the safe verdict), bumps errorCount() and leaves the text in lastError() (and in
+// mvk_last_error() of the calling thread).  Only the constructors throw (a null or foreign ctx is a programming error).
 #ifndef MVK_OMPL_ADAPTER_HPP_
 #define MVK_OMPL_ADAPTER_HPP_
 
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -80,6 +88,39 @@ struct SE3StateSpace {
     const SO3StateSpace::StateType& rotation() const { return rot_; }
     SO3StateSpace::StateType& rotation() { return rot_; }
   };
+};
+class SpaceInformation {};
+typedef std::shared_ptr<SpaceInformation> SpaceInformationPtr;
+// ompl/base/StateValidityChecker.h: the virtuals an override must not hide
+class StateValidityChecker {
+ public:
+  explicit StateValidityChecker(const SpaceInformationPtr& si) : si_(si.get()) {}
+  virtual ~StateValidityChecker() = default;
+  virtual bool isValid(const State* state) const = 0;
+  virtual bool isValid(const State* state, double& dist) const {
+    dist = clearance(state);
+    return isValid(state);
+  }
+  virtual double clearance(const State*) const { return 0.0; }
+
+ protected:
+  SpaceInformation* si_;
+};
+// ompl/base/MotionValidator.h
+class MotionValidator {
+ public:
+  explicit MotionValidator(const SpaceInformationPtr& si) : si_(si.get()) {}
+  virtual ~MotionValidator() = default;
+  virtual bool checkMotion(const State* s1, const State* s2) const = 0;
+  virtual bool checkMotion(const State* s1, const State* s2, std::pair<State*, double>& lastValid) const = 0;
+  unsigned int getValidMotionCount() const { return valid_; }
+  unsigned int getInvalidMotionCount() const { return invalid_; }
+  void resetMotionCounter() { valid_ = invalid_ = 0; }
+
+ protected:
+  SpaceInformation* si_;
+  mutable unsigned int valid_ = 0;
+  mutable unsigned int invalid_ = 0;
 };
 }  // namespace base
 }  // namespace ompl
@@ -147,33 +188,50 @@ inline void unflatten_state(const mvk_params& p, int n_joint, const double* in, 
   }
 }
 
-// ompl::base::StateValidityChecker look-alike (derive from the real class when
-// OMPL headers are present: the member signatures are identical).
-class StateValidityChecker
-#ifndef MVK_OMPL_STUB
-    : public ompl::base::StateValidityChecker
-#endif
-{
+namespace detail {
+// error bookkeeping shared by both adapters: nothing is thrown into OMPL's loops
+class ErrorLog {
  public:
-#ifndef MVK_OMPL_STUB
-  StateValidityChecker(const ompl::base::SpaceInformationPtr& si, mvk_ctx* ctx, int n_joint)
-      : ompl::base::StateValidityChecker(si), ctx_(ctx), n_joint_(n_joint) { init(); }
-#else
-  StateValidityChecker(mvk_ctx* ctx, int n_joint) : ctx_(ctx), n_joint_(n_joint) { init(); }
-  virtual ~StateValidityChecker() = default;
-#endif
+  unsigned errorCount() const { return errors_; }
+  const std::string& lastError() const { return last_error_; }
 
-  // replaces MotionPlanning::isStateValid (motion_planning.cpp:76-164)
-  virtual bool isValid(const ompl::base::State* state) const {
+ protected:
+  bool ok(int rc) const {
+    if (rc == MVK_OK) return true;
+    ++errors_;
+    last_error_ = mvk_last_error();
+    return false;
+  }
+  static mvk_params params_of(mvk_ctx* ctx) {
+    mvk_params p{};
+    if (mvk_get_params(ctx, &p) != MVK_OK) throw std::invalid_argument(std::string("mvk adapter: ") + mvk_last_error());
+    return p;
+  }
+  mutable unsigned errors_ = 0;
+  mutable std::string last_error_;
+};
+}  // namespace detail
+
+// replaces the functor bound at motion_planning.cpp:236,247,257
+class StateValidityChecker : public ompl::base::StateValidityChecker, public detail::ErrorLog {
+ public:
+  StateValidityChecker(const ompl::base::SpaceInformationPtr& si, mvk_ctx* ctx, int n_joint)
+      : ompl::base::StateValidityChecker(si), ctx_(ctx), n_joint_(n_joint), params_(params_of(ctx)) {}
+
+  // the base class's isValid(state, dist) / clearance() stay visible next to the batched overload below
+  using ompl::base::StateValidityChecker::isValid;
+
+  // MotionPlanning::isStateValid (motion_planning.cpp:76-164)
+  bool isValid(const ompl::base::State* state) const override {
     double s[MVK_MAX_STATE_DIM];
     flatten_state(params_, n_joint_, state, s);
     // the flag path (a batch of one): the verdict alone, without the distances mvk_is_valid also reports
     std::uint8_t flag = 0;
-    check(mvk_is_valid_batch(ctx_, s, 1, 1, MVK_LAYOUT_OMPL, &flag, nullptr, nullptr, nullptr));
+    if (!ok(mvk_is_valid_batch(ctx_, s, 1, 1, MVK_LAYOUT_OMPL, &flag, nullptr, nullptr, nullptr))) return false;
     return flag != 0;
   }
 
-  // batched isValid(states[N]): one kernel launch for all N states
+  // batched isValid(states[N]): one kernel launch for all N states; on an error every out[i] = 0
   virtual void isValid(const ompl::base::State* const* states, std::size_t n, std::uint8_t* out) const {
     if (n == 0) return;
     const int dim = mvk_space_dim(&params_, n_joint_);
@@ -183,7 +241,8 @@ class StateValidityChecker
       flatten_state(params_, n_joint_, states[i], s);
       for (int r = 0; r < dim; ++r) soa[static_cast<std::size_t>(r) * n + i] = s[r];
     }
-    check(mvk_is_valid_batch(ctx_, soa.data(), n, n, MVK_LAYOUT_OMPL, out, nullptr, nullptr, nullptr));
+    if (!ok(mvk_is_valid_batch(ctx_, soa.data(), n, n, MVK_LAYOUT_OMPL, out, nullptr, nullptr, nullptr)))
+      for (std::size_t i = 0; i < n; ++i) out[i] = 0;
   }
 
   const mvk_params& params() const { return params_; }
@@ -191,54 +250,48 @@ class StateValidityChecker
   int jointCount() const { return n_joint_; }
 
  protected:
-  static void check(int rc) {
-    if (rc != MVK_OK) throw std::runtime_error(std::string("mvk: ") + mvk_last_error());
-  }
-  void init() { check(mvk_get_params(ctx_, &params_)); }
   mvk_ctx* ctx_;
   int n_joint_;
-  mvk_params params_{};
+  mvk_params params_;
 };
 
-// ompl::base::DiscreteMotionValidator look-alike: the whole edge is densified and
-// checked by ONE kernel launch (order of evaluation does not change the Boolean).
-class MotionValidator
-#ifndef MVK_OMPL_STUB
-    : public ompl::base::MotionValidator
-#endif
-{
+// replaces ompl::base::DiscreteMotionValidator installed at motion_planning.cpp:238,249 (and OMPL's default in
+// mode 2): the whole edge is densified and checked by ONE kernel launch (the order of evaluation does not
+// change the Boolean; lastValid comes from the smallest invalid step).
+class MotionValidator : public ompl::base::MotionValidator, public detail::ErrorLog {
  public:
-#ifndef MVK_OMPL_STUB
   MotionValidator(const ompl::base::SpaceInformationPtr& si, mvk_ctx* ctx, int n_joint)
-      : ompl::base::MotionValidator(si), ctx_(ctx), n_joint_(n_joint) { init(); }
-#else
-  MotionValidator(mvk_ctx* ctx, int n_joint) : ctx_(ctx), n_joint_(n_joint) { init(); }
-  virtual ~MotionValidator() = default;
-#endif
+      : ompl::base::MotionValidator(si), ctx_(ctx), n_joint_(n_joint), params_(params_of(ctx)) {}
 
-  virtual bool checkMotion(const ompl::base::State* s1, const ompl::base::State* s2) const {
-    int first = 0;
-    return run(s1, s2, first) != 0;
+  bool checkMotion(const ompl::base::State* s1, const ompl::base::State* s2) const override {
+    Edge e;
+    const bool valid = run(s1, s2, e) && e.first == e.nd + 1;
+    count(valid);
+    return valid;
   }
 
-  // lastValid.first (if non-null) receives interpolate(s1, s2, lastValid.second), as OMPL does
-  virtual bool checkMotion(const ompl::base::State* s1, const ompl::base::State* s2,
-                           std::pair<ompl::base::State*, double>& lastValid) const {
-    int first = 0;
-    double a[MVK_MAX_STATE_DIM], b[MVK_MAX_STATE_DIM], m[MVK_MAX_STATE_DIM];
-    const int nd = run(s1, s2, first, a, b);
-    if (first == nd + 1) return true;
-    lastValid.second = static_cast<double>(first - 1) / static_cast<double>(nd);
-    if (lastValid.first) {
-      mvk_space_interpolate(&params_, n_joint_, a, b, lastValid.second, m);
-      unflatten_state(params_, n_joint_, m, lastValid.first);
+  // DiscreteMotionValidator semantics: on failure lastValid.second = (first invalid step - 1) / nd and
+  // lastValid.first (if non-null) receives interpolate(s1, s2, lastValid.second)
+  bool checkMotion(const ompl::base::State* s1, const ompl::base::State* s2,
+                   std::pair<ompl::base::State*, double>& lastValid) const override {
+    Edge e;
+    const bool ran = run(s1, s2, e);
+    const bool valid = ran && e.first == e.nd + 1;
+    if (!valid) {
+      lastValid.second = ran ? static_cast<double>(e.first - 1) / static_cast<double>(e.nd) : 0.0;
+      if (lastValid.first) {
+        double m[MVK_MAX_STATE_DIM];
+        mvk_space_interpolate(&params_, n_joint_, e.a, e.b, lastValid.second, m);
+        unflatten_state(params_, n_joint_, m, lastValid.first);
+      }
     }
-    return false;
+    count(valid);
+    return valid;
   }
 
-  // batched form used by planners that grow many edges per iteration
+  // batched form used by planners that grow many edges per iteration; on an error every ok[e] = 0
   void checkMotions(const ompl::base::State* const* from, const ompl::base::State* const* to, std::size_t n,
-                    std::uint8_t* ok, std::int32_t* first_invalid /*nullable*/) const {
+                    std::uint8_t* ok_out, std::int32_t* first_invalid /*nullable*/) const {
     if (n == 0) return;
     const int dim = mvk_space_dim(&params_, n_joint_);
     std::vector<double> a(static_cast<std::size_t>(dim) * n), b(a.size());
@@ -253,33 +306,41 @@ class MotionValidator
         b[static_cast<std::size_t>(r) * n + e] = y[r];
       }
     }
-    check(mvk_check_motion_batch(ctx_, a.data(), b.data(), n, n, nd.data(), 0, ok, first_invalid));
+    if (!ok(mvk_check_motion_batch(ctx_, a.data(), b.data(), n, n, nd.data(), 0, ok_out, first_invalid))) {
+      for (std::size_t e = 0; e < n; ++e) {
+        ok_out[e] = 0;
+        if (first_invalid) first_invalid[e] = 1;
+      }
+    }
+    for (std::size_t e = 0; e < n; ++e) count(ok_out[e] != 0);
   }
 
+  const mvk_params& params() const { return params_; }
+
  protected:
-  // returns nd (>= 1); first = smallest invalid step or nd + 1
-  int run(const ompl::base::State* s1, const ompl::base::State* s2, int& first, double* a_out = nullptr,
-          double* b_out = nullptr) const {
+  struct Edge {
     double a[MVK_MAX_STATE_DIM], b[MVK_MAX_STATE_DIM];
-    flatten_state(params_, n_joint_, s1, a);
-    flatten_state(params_, n_joint_, s2, b);
-    int nd = mvk_space_valid_segment_count(&params_, n_joint_, a, b);
-    if (nd < 1) nd = 1;
-    std::uint8_t ok = 0;
-    std::int32_t fi = 0;
-    check(mvk_check_motion_batch(ctx_, a, b, 1, 1, nullptr, nd, &ok, &fi));
-    first = fi;
-    const int dim = mvk_space_dim(&params_, n_joint_);
-    if (a_out) for (int r = 0; r < dim; ++r) { a_out[r] = a[r]; b_out[r] = b[r]; }
-    return ok ? (first = nd + 1, nd) : nd;
+    int nd = 1;     // validSegmentCount(s1, s2), at least 1
+    int first = 1;  // smallest invalid step j in 1..nd, or nd + 1 when every step is valid
+  };
+  // false when the C-ABI call failed (the edge then counts as invalid from its first step)
+  bool run(const ompl::base::State* s1, const ompl::base::State* s2, Edge& e) const {
+    flatten_state(params_, n_joint_, s1, e.a);
+    flatten_state(params_, n_joint_, s2, e.b);
+    e.nd = mvk_space_valid_segment_count(&params_, n_joint_, e.a, e.b);
+    if (e.nd < 1) e.nd = 1;
+    std::int32_t fi = 1;
+    if (!ok(mvk_check_motion_batch(ctx_, e.a, e.b, 1, 1, nullptr, e.nd, nullptr, &fi))) return false;
+    e.first = fi;
+    return true;
   }
-  static void check(int rc) {
-    if (rc != MVK_OK) throw std::runtime_error(std::string("mvk: ") + mvk_last_error());
+  void count(bool valid) const {
+    if (valid) ++valid_;
+    else ++invalid_;
   }
-  void init() { check(mvk_get_params(ctx_, &params_)); }
   mvk_ctx* ctx_;
   int n_joint_;
-  mvk_params params_{};
+  mvk_params params_;
 };
 
 }  // namespace mvk

@@ -119,6 +119,13 @@ struct mvk_ctx {
   float f32_delta = 0.0f;
   double f32_range = 0.0;
   hipStream_t stream = nullptr;
+  // Calls on one ctx share its scratch (queues, records, counters, statistics partials, staging), so they must
+  // execute in the order they were issued even when the caller hands different streams to the _dev entry points:
+  // every call that touches the scratch records `order_ev` behind its work, and a call on another stream makes
+  // that stream wait for it first (enter_stream / leave_stream).
+  hipEvent_t order_ev = nullptr;
+  hipStream_t order_stream = nullptr;
+  bool order_armed = false;
   // staging for the host-pointer entry points
   Buf in_a, in_b, flags, band, mind, margin, det[6], nd, ok, first, edge_off, av[7];
   // host edge checks (the planner's inner loop): one pinned upload blob, one pinned download
@@ -434,6 +441,19 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
   a.nd_uniform = 1;
 }
 
+// Ordering of the calls that use the ctx's scratch buffers (see mvk_ctx::order_ev): a call on a stream other than
+// the last one's first makes its stream wait for the last call's work; every call leaves its own mark behind.
+int enter_stream(mvk_ctx* c, hipStream_t s) {
+  if (c->order_armed && s != c->order_stream) HIP_TRY(hipStreamWaitEvent(s, c->order_ev, 0));
+  return MVK_OK;
+}
+int leave_stream(mvk_ctx* c, hipStream_t s) {
+  HIP_TRY(hipEventRecord(c->order_ev, s));
+  c->order_stream = s;
+  c->order_armed = true;
+  return MVK_OK;
+}
+
 // flag path: size the hand-off buffers between the screen stage and the exact stage for n lanes and
 // hand this call its set of counters
 int prepare_queue(mvk_ctx* c, EvalArgs& a, uint64_t n) {
@@ -494,11 +514,12 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
   } else if (int rc = prepare_queue(c, a, n)) {
     return rc;
   }
+  if (int rc = enter_stream(c, s)) return rc;
   const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s, c->profiling ? c->ev : nullptr);
   c->timed = c->profiling;
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
   c->stats_valid = a.full != 0;
-  return MVK_OK;
+  return leave_stream(c, s);
 }
 
 // copy a [rows][n] SoA block with row pitch ld (elements) between host and device
@@ -590,6 +611,7 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  if ((e = hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_model), sizeof(mvk_model))) != hipSuccess) return bail("hipMalloc(model)", e);
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_extras), sizeof(DevExtras))) != hipSuccess) return bail("hipMalloc(extras)", e);
   if ((e = hipMemcpy(c->d_model, &c->model, sizeof(mvk_model), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload model", e);
@@ -609,12 +631,14 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
 extern "C" void mvk_destroy(mvk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->order_armed) (void)hipEventSynchronize(c->order_ev);  // the last call may be on a caller's stream
   if (c->stream) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
   }
   for (hipEvent_t& e : c->ev)
     if (e) (void)hipEventDestroy(e);
+  if (c->order_ev) (void)hipEventDestroy(c->order_ev);
   if (c->d_model) (void)hipFree(c->d_model);
   if (c->d_extras) (void)hipFree(c->d_extras);
   Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start[0], &c->dgrid_items[0], &c->dgrid_start[1], &c->dgrid_items[1], &c->queue, &c->queue_rec, &c->queue_counts, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
@@ -712,10 +736,11 @@ extern "C" int mvk_sweep_mask_dev(mvk_ctx* c, const double* root_pose7, uint64_t
   }
   c->stats_valid = false;
   if (int rc = prepare_queue(c, a, n)) return rc;
+  if (int rc = enter_stream(c, static_cast<hipStream_t>(stream))) return rc;
   const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, static_cast<hipStream_t>(stream), c->profiling ? c->ev : nullptr);
   c->timed = c->profiling;
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
-  return MVK_OK;
+  return leave_stream(c, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mvk_sweep_states(const mvk_params* prm, int J, const double* root_pose7, uint64_t first_index, size_t n,
@@ -755,6 +780,7 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
   if (rows < 0) return rows;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
+  if (int rc = enter_stream(c, s)) return rc;  // the staging buffers may still feed a call on a caller's stream
   const size_t dld = round_up(n, 64);
   const int NL = c->model.n_rotor;
   if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
@@ -923,20 +949,24 @@ extern "C" int mvk_collision_avoidance_batch_dev(mvk_ctx* c, const double* d_soa
   a.av_dist = o->dist; a.av_box = o->box; a.av_p_env = o->p_env; a.av_p_robot = o->p_robot;
   a.av_row = o->row; a.av_lb = o->lb; a.av_ok = o->ok;
   c->stats_valid = false;
+  if (int rc = enter_stream(c, static_cast<hipStream_t>(stream))) return rc;
   const int e = launch_avoid(a, c->model.robot_type, c->model.n_rotor, stream);
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "avoidance kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
-  return MVK_OK;
+  return leave_stream(c, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mvk_collision_avoidance_batch(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout,
                                              const mvk_avoid_params* prm, const mvk_avoid_out* o) {
   if (!c || !prm || !o) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  if (c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (n == 0) return MVK_OK;
   if (!soa || ld < n) return fail(MVK_ERR_INVALID_ARG, "bad state array (null, or ld < n)");
+  if (!(prm->constraint_range > prm->forbidden_range)) return fail(MVK_ERR_INVALID_ARG, "constraint_range must exceed forbidden_range");
   const int rows = layout_rows(c, layout);
   if (rows < 0) return rows;
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
+  if (int rc = enter_stream(c, s)) return rc;  // the staging buffers may still feed a call on a caller's stream
   const size_t dld = round_up(n, 64), P = static_cast<size_t>(c->model.n_prim), W = 6 + static_cast<size_t>(c->model.n_joint);
   if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
   if (int rc = copy_rows(c->in_a.p, dld, soa, ld, sizeof(double), n, rows, hipMemcpyHostToDevice, s)) return rc;
@@ -982,12 +1012,13 @@ int run_edges_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_e
   a.first_invalid = d_first;
   c->stats_valid = false;
   if (int rc = prepare_queue(c, a, total)) return rc;
+  if (int rc = enter_stream(c, s)) return rc;
   int e = first_is_initialised ? static_cast<int>(hipSuccess) : launch_edge_init(d_first, d_nd, a.nd_uniform, n_edges, s);
   if (e == hipSuccess) e = launch_eval(a, c->model.robot_type, c->model.n_rotor, true, s, c->profiling ? c->ev : nullptr);
   c->timed = c->profiling;
   if (e == hipSuccess && d_ok) e = launch_edge_finish(d_first, d_nd, a.nd_uniform, d_ok, n_edges, s);
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "edge kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
-  return MVK_OK;
+  return leave_stream(c, s);
 }
 
 int prefix_counts(const int32_t* nd, size_t n, std::vector<int64_t>& off, uint64_t& total) {
@@ -1090,6 +1121,7 @@ extern "C" int mvk_check_motion_batch_begin(mvk_ctx* c, const double* s1, const 
     }
   }
   char* dev = static_cast<char*>(c->edge_blob.p);
+  if (int rc = enter_stream(c, s)) return rc;
   HIP_TRY(hipMemcpyAsync(dev, up, bytes, hipMemcpyHostToDevice, s));
   if (int rc = run_edges_dev(c, reinterpret_cast<const double*>(dev), reinterpret_cast<const double*>(dev + off_s2), n_edges, dld,
                              nd ? reinterpret_cast<const int32_t*>(dev + off_nd) : nullptr,
@@ -1110,9 +1142,10 @@ extern "C" int mvk_check_motion_batch_end(mvk_ctx* c, uint8_t* ok, int32_t* firs
   c->edges_pending = false;
   const size_t n_edges = c->edges_in_flight;
   if (n_edges == 0) return MVK_OK;
-  if (!ok && !first_invalid) return fail(MVK_ERR_INVALID_ARG, "no output requested");
+  // wait first, whatever the arguments: once the ctx reads as idle nothing may still be using its pinned blocks
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!ok && !first_invalid) return fail(MVK_ERR_INVALID_ARG, "no output requested");
   const int32_t* down = static_cast<const int32_t*>(c->pin_down.p);
   const int32_t* hnd = reinterpret_cast<const int32_t*>(static_cast<const char*>(c->pin_up.p) + c->edges_nd_off);
   for (size_t e = 0; e < n_edges; ++e) {

@@ -178,7 +178,7 @@ bool kernel_supported(int robot_type, int n_links);
 
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): the counter-based
 // generator of the C-space sweep.  Shared by host and device code so that both produce the same states.
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MVK_HD __host__ __device__ inline
 #else
 #define MVK_HD inline

@@ -92,7 +92,9 @@ class Workers {
   int count() const { return static_cast<int>(th_.size()) + 1; }
   // runs fn(k) for k in [0, n), the caller taking part
   void parallel_for(int n, const std::function<void(int)>& fn) {
-    if (n <= 1 || th_.empty()) {
+    // one job at a time: a second planner (another thread, another ctx) that finds the pool busy runs its loop itself
+    std::unique_lock<std::mutex> busy(busy_, std::try_to_lock);
+    if (n <= 1 || th_.empty() || !busy.owns_lock()) {
       for (int k = 0; k < n; ++k) fn(k);
       return;
     }
@@ -113,6 +115,7 @@ class Workers {
 
  private:
   static void cpu_relax() { __builtin_ia32_pause(); }
+  std::mutex busy_;
   // take jobs of `epoch` until none is left (or the epoch has moved on: a late worker does nothing)
   void work(uint64_t epoch, const std::function<void(int)>* fn, int n) {
     for (;;) {
@@ -332,6 +335,8 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
                                        mvk_plan_result* out) {
   if (!params || !ck || !ck->check_states || !ck->check_motions || !req || !req->start || !req->goal || !out)
     return fail(MVK_ERR_INVALID_ARG, "mvk_plan_rrt_connect: null argument");
+  if ((ck->check_motions_begin == nullptr) != (ck->check_motions_end == nullptr))
+    return fail(MVK_ERR_INVALID_ARG, "mvk_plan_rrt_connect: check_motions_begin and check_motions_end go together (both or neither)");
   const mvk_params& p = *params;
   const int dim = space_dim(&p, J);
   std::memset(out, 0, sizeof(*out));
@@ -391,11 +396,11 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
   // the edge check in two halves, so that host work can run while the GPU checks (a checker
   // without the split interface does all its work in the second half)
   auto check_begin = [&](size_t n) -> int {
-    return ck->check_motions_begin ? ck->check_motions_begin(ck->user, eb.a.data(), eb.b.data(), n, n, eb.nd.data()) : 0;
+    return merged ? ck->check_motions_begin(ck->user, eb.a.data(), eb.b.data(), n, n, eb.nd.data()) : 0;
   };
   auto check_end = [&](size_t n) -> int {
-    return ck->check_motions_begin ? ck->check_motions_end(ck->user, eb.ok.data(), eb.first.data())
-                                   : ck->check_motions(ck->user, eb.a.data(), eb.b.data(), n, n, eb.nd.data(), eb.ok.data(), eb.first.data());
+    return merged ? ck->check_motions_end(ck->user, eb.ok.data(), eb.first.data())
+                  : ck->check_motions(ck->user, eb.a.data(), eb.b.data(), n, n, eb.nd.data(), eb.ok.data(), eb.first.data());
   };
   while (!solved) {
     if (req->max_iterations > 0 && out->iterations >= static_cast<uint64_t>(req->max_iterations)) break;
@@ -625,8 +630,15 @@ extern "C" int mvk_path_log_load(const char* file, int J, mvk_path_log* h, doubl
   h->n_joint = J;
   const int w = 7 + J;
   std::string line, header;
+  // the reference's savePath leaves J - 1 blank lines after every state (quirk Q6, motion_planning.cpp:682-684):
+  // lines without a token are skipped, so its files load as well as the ones mvk_path_log_save writes
+  auto next_line = [&]() -> bool {
+    while (std::getline(ifs, line))
+      if (line.find_first_not_of(" \t\r") != std::string::npos) return true;
+    return false;
+  };
   auto read_row = [&](double* dst) -> bool {
-    if (!std::getline(ifs, line)) return false;
+    if (!next_line()) return false;
     std::stringstream ss(line);
     ss >> header;
     for (int i = 0; i < w; ++i)
@@ -635,7 +647,7 @@ extern "C" int mvk_path_log_load(const char* file, int J, mvk_path_log* h, doubl
   };
   if (!read_row(h->start) || !read_row(h->goal)) return fail(MVK_ERR_IO, "%s: malformed start/goal line", file);
   auto read_kv = [&](auto& dst) -> bool {
-    if (!std::getline(ifs, line)) return false;
+    if (!next_line()) return false;
     std::stringstream ss(line);
     ss >> header >> dst;
     return !ss.fail();

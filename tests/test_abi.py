@@ -93,8 +93,9 @@ def test_headers_compile_as_c_and_cpp(tmp_path):
 #define MVK_OMPL_STUB
 #include "mvk_ompl_adapter.hpp"
 int use(mvk_ctx* ctx) {
-  mvk::StateValidityChecker svc(ctx, 3);
-  mvk::MotionValidator mv(ctx, 3);
+  auto si = std::make_shared<ompl::base::SpaceInformation>();
+  mvk::StateValidityChecker svc(si, ctx, 3);
+  mvk::MotionValidator mv(si, ctx, 3);
   ompl::base::SE2StateSpace::StateType b1, b2; double j1[3] = {0, 0, 0}, j2[3] = {1, 1, 1};
   ompl::base::RealVectorStateSpace::StateType r1, r2; r1.values = j1; r2.values = j2;
   ompl::base::State* c1[2] = {&b1, &r1}; ompl::base::State* c2[2] = {&b2, &r2};
@@ -102,7 +103,15 @@ int use(mvk_ctx* ctx) {
   std::pair<ompl::base::State*, double> last(&s1, 0.0);
   const ompl::base::State* many[2] = {&s1, &s2}; std::uint8_t out[2];
   svc.isValid(many, 2, out);
-  return svc.isValid(&s1) + mv.checkMotion(&s1, &s2) + mv.checkMotion(&s1, &s2, last);
+  double dist = 0.0;
+  return svc.isValid(&s1) + svc.isValid(&s1, dist) + mv.checkMotion(&s1, &s2) + mv.checkMotion(&s1, &s2, last);
 }
 ''')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+
+
+def test_adapter_check_library_is_built_and_exports_its_entry_points():
+    """the runnable form of the adapter (csrc/mvk_adapter_check.cpp); it is RUN by tests/test_gpu_adapter.py"""
+    A.load()
+    lib = C.CDLL(os.path.join(os.path.dirname(A.lib_path()), "libmvk_adapter_check.so"))
+    assert hasattr(lib, "mvk_adapter_check_run") and hasattr(lib, "mvk_adapter_check_errors")

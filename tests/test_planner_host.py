@@ -89,3 +89,40 @@ def test_rrt_connect_reports_invalid_start_and_no_solution():
     cs, cm = oracle_checker(model, sealed, params)
     wp, info = PL.plan_rrt_connect_cb(params, 3, cs, cm, start, goal, time_limit_s=30.0, max_iterations=15, batch=4)
     assert wp is None and info["solved"] == 0 and info["iterations"] == 15
+
+
+def test_path_log_load_reads_the_reference_savepath_format(tmp_path):
+    """savePath of the reference's current code prints J newlines after every state (motion_planning.cpp:682-684,
+    quirk Q6): J - 1 blank lines between states.  ADVICE r1: such a file must load."""
+    lines = open(LOG).read().splitlines()
+    out = []
+    for ln in lines:
+        out.append(ln)
+        if ln.startswith("state") and not ln.startswith("states"):
+            out += ["", ""]          # J = 3: two blank lines
+    f = tmp_path / "q6.txt"
+    f.write_text("\n".join(out) + "\n")
+    hdr, states = PL.load_path_log(f, 3)
+    assert hdr["n_states"] == 235 and np.array_equal(states, load_states())
+    # the mode-1 log of the reference (ten values per state, J = 3) loads too
+    hdr1, st1 = PL.load_path_log(os.path.join(os.path.dirname(LOG), "ref_hydrus_planning_log_mode1.txt"), 3)
+    assert hdr1["n_states"] == 390 and hdr1["planning_mode"] == 1 and st1.shape == (390, 10)
+    assert hdr1["planning_time"] == pytest.approx(0.208125)
+
+
+def test_checker_with_half_a_split_interface_is_rejected():
+    """begin without end used to crash in check_end"""
+    import ctypes as C
+    model, params, boxes, start, goal = common.config1()
+    lib = A.load()
+    noop_s = A.CHECK_STATES_FN(lambda *a: 0)
+    noop_m = A.CHECK_MOTIONS_FN(lambda *a: 0)
+    begin = C.cast(C.CFUNCTYPE(C.c_int)(lambda: 0), C.c_void_p)
+    ck = A.Checker(noop_s, noop_m, None, begin, None)
+    s = np.ascontiguousarray(start)
+    g = np.ascontiguousarray(goal)
+    req = A.PlanRequest(s.ctypes.data_as(C.POINTER(C.c_double)), g.ctypes.data_as(C.POINTER(C.c_double)), 0.0, 1.0, 1, 1, 4)
+    wp = np.zeros((16, 6))
+    res = A.PlanResult()
+    rc = lib.mvk_plan_rrt_connect_cb(C.byref(params), 3, C.byref(ck), C.byref(req), wp.ctypes.data_as(C.c_void_p), 16, C.byref(res))
+    assert rc == A.ERR_INVALID_ARG and b"both or neither" in lib.mvk_last_error()
