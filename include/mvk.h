@@ -270,6 +270,20 @@ int mvk_is_valid_batch_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t l
 int mvk_is_valid_mask_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout,
                           uint64_t* d_mask, void* stream);
 
+/* mvk_is_valid_mask_dev for callers that cannot allocate.  No counterpart in the reference; it is for
+ * callers that must not reach hipMalloc / hipFree: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  The other batched entry points keep grow-only buffers per ctx and
+ * may allocate when a batch is larger than any before; this one allocates nothing, ever: the flag
+ * path's hand-off queues, records and counters live in one file-scope __device__ array of the library
+ * (22.1 MiB per GPU, held until the process ends), so
+ *   - n is limited to MVK_NOALLOC_MAX_STATES per call (MVK_ERR_CAPACITY beyond, nothing is launched);
+ *   - every ctx on one GPU shares that array: calls of this entry point that overlap on one GPU
+ *     (two streams, two ctxs, two threads) race.  Issue them one after another in stream order.
+ * Same arguments, same result bits as mvk_is_valid_mask_dev (tests/test_zz_no_alloc.py). */
+#define MVK_NOALLOC_MAX_STATES 65536
+int mvk_is_valid_mask_noalloc_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout,
+                                  uint64_t* d_mask, void* stream);
+
 /* C-space sweep (BASELINE config 5; the reference's manual joint-space validity sweep is
  * sampling_based_method/scripts/state_validation_l4.py:46-68).  Sample i (i = first_index ..
  * first_index + n - 1) has the fixed root pose `root_pose7` (px py pz qx qy qz qw) and joints

@@ -16,6 +16,7 @@ ROBOT_HYDRUS, ROBOT_DRAGON = 0, 1
 PRIM_SPHERE, PRIM_CAPSULE, PRIM_BOX = 0, 1, 2
 FRAME_SEG, FRAME_GIMBAL_ROLL, FRAME_GIMBAL_PITCH = 0, 1, 2
 LAYOUT_POSE7, LAYOUT_OMPL = 0, 1
+NOALLOC_MAX_STATES = 65536
 
 d, i32 = C.c_double, C.c_int32
 
@@ -135,6 +136,7 @@ PROTOTYPES = {
     "mvk_is_valid_batch": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp]),
     "mvk_is_valid_batch_dev": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, vp]),
     "mvk_is_valid_mask_dev": (ip, [vp, vp, sz, sz, ip, vp, vp]),
+    "mvk_is_valid_mask_noalloc_dev": (ip, [vp, vp, sz, sz, ip, vp, vp]),
     "mvk_sweep_mask_dev": (ip, [vp, vp, C.c_uint64, sz, C.c_uint64, vp, vp]),
     "mvk_sweep_states": (ip, [PP, ip, vp, C.c_uint64, sz, C.c_uint64, vp, sz]),
     "mvk_mask_count_dev": (ip, [vp, sz, vp, vp]),

@@ -119,6 +119,7 @@ struct mvk_ctx {
   float f32_delta = 0.0f;
   double f32_range = 0.0;
   hipStream_t stream = nullptr;
+  void* static_scratch = nullptr;  // this GPU's copy of the no-allocation entry point's scratch array (resolved at mvk_create)
   // Calls on one ctx share its scratch (queues, records, counters, statistics partials, staging), so they must
   // execute in the order they were issued even when the caller hands different streams to the _dev entry points:
   // every call that touches the scratch records `order_ev` behind its work, and a call on another stream makes
@@ -612,6 +613,8 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
   if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   if ((e = hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = static_cast<hipError_t>(static_scratch_for_current_device(device, &c->static_scratch))) != hipSuccess)
+    return bail("hipGetSymbolAddress(scratch)", e);
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_model), sizeof(mvk_model))) != hipSuccess) return bail("hipMalloc(model)", e);
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_extras), sizeof(DevExtras))) != hipSuccess) return bail("hipMalloc(extras)", e);
   if ((e = hipMemcpy(c->d_model, &c->model, sizeof(mvk_model), hipMemcpyHostToDevice)) != hipSuccess) return bail("upload model", e);
@@ -712,6 +715,53 @@ extern "C" int mvk_is_valid_mask_dev(mvk_ctx* c, const double* d_soa, size_t n, 
   if (!d_mask) return fail(MVK_ERR_INVALID_ARG, "null mask");
   return run_eval_dev(c, d_soa, n, ld, layout, nullptr, d_mask, nullptr, nullptr, nullptr, nullptr, false,
                       static_cast<hipStream_t>(stream));
+}
+
+// The flag path with its hand-off buffers in the library's static __device__ scratch array: no hipMalloc, no
+// hipFree, no allocating routine on this path (the ctx's grow-only buffers are not touched).
+extern "C" int mvk_is_valid_mask_noalloc_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout,
+                                             uint64_t* d_mask, void* stream) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  if (c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
+  if (!d_mask) return fail(MVK_ERR_INVALID_ARG, "null mask");
+  if (n == 0) return MVK_OK;
+  if (n > MVK_NOALLOC_MAX_STATES)
+    return fail(MVK_ERR_CAPACITY, "mvk_is_valid_mask_noalloc_dev: %zu states exceed the static scratch (at most %d per call)", n, MVK_NOALLOC_MAX_STATES);
+  if (!d_soa || ld < n) return fail(MVK_ERR_INVALID_ARG, "bad state array (null, or ld < n)");
+  const int rows = layout_rows(c, layout);
+  if (rows < 0) return rows;
+  if (!c->static_scratch) return fail(MVK_ERR_HIP, "static scratch not resolved on device %d", c->device);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  EvalArgs a;
+  base_args(c, a);
+  a.soa = d_soa;
+  a.n = n;
+  a.ld = ld;
+  a.layout = layout;
+  a.mask = d_mask;
+  // scratch layout: [counter set of this call][counter set the kernel zeroes "for the next call"][queues][records]
+  unsigned char* base = static_cast<unsigned char*>(c->static_scratch);
+  const uint64_t waves = (n + kBlock - 1) / kBlock * (kBlock / 64);
+  a.queue_stride = (waves + kQueueShards - 1) / kQueueShards * 64;
+  a.queue_count = reinterpret_cast<uint32_t*>(base);
+  a.queue_count_next = reinterpret_cast<uint32_t*>(base + kStaticCounterSetBytes);
+  a.queue = reinterpret_cast<uint32_t*>(base + 2 * kStaticCounterSetBytes);
+  a.queue_rec = reinterpret_cast<double*>(base + 2 * kStaticCounterSetBytes + kStaticQueueBytes);
+  a.exact_blocks = static_cast<uint32_t>(3 * c->n_cu);
+  // what the kernels use must fit what the array holds (n <= MVK_NOALLOC_MAX_STATES and the model's capacities)
+  const uint64_t need_queue = static_cast<uint64_t>(c->model.n_seg) * kQueueShards * a.queue_stride * sizeof(uint32_t);
+  const uint64_t need_rec = waves * 64 * (8 + 2 * static_cast<uint64_t>(c->model.n_joint)) * sizeof(double);
+  if (need_queue > kStaticQueueBytes || need_rec > kStaticRecordBytes)
+    return fail(MVK_ERR_CAPACITY, "mvk_is_valid_mask_noalloc_dev: batch does not fit the static scratch");
+  c->stats_valid = false;
+  if (int rc = enter_stream(c, s)) return rc;
+  // the array keeps the last call's contents (any ctx of this GPU): the counters must start at zero
+  HIP_TRY(hipMemsetAsync(base, 0, kStaticCounterSetBytes, s));
+  const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s, c->profiling ? c->ev : nullptr);
+  c->timed = c->profiling;
+  if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+  return leave_stream(c, s);
 }
 
 extern "C" int mvk_sweep_mask_dev(mvk_ctx* c, const double* root_pose7, uint64_t first_index, size_t n, uint64_t seed,

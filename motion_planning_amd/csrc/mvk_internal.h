@@ -166,6 +166,18 @@ constexpr int kQueueShards = 8;         // queues per segment (MVK_MAX_SEG * kQu
 constexpr int kQueueCounterPitch = 64;  // uint32 words between two counters: one 256-byte line each
 
 
+// ---- the no-allocation flag path (mvk_is_valid_mask_noalloc_dev) -------------------------------------------
+// Its hand-off buffers live in ONE file-scope __device__ array of mvk_kernels.hip instead of ctx-owned hipMalloc
+// memory: [counter set][counter set][queues][records], sized for MVK_NOALLOC_MAX_STATES states of the largest
+// model the blob can describe (MVK_MAX_SEG segments, MVK_MAX_JOINT joints).  Every GPU holds its own copy.
+constexpr size_t kStaticCounterSetBytes = static_cast<size_t>(MVK_MAX_SEG) * kQueueShards * kQueueCounterPitch * sizeof(uint32_t);
+constexpr size_t kStaticQueueBytes = static_cast<size_t>(MVK_MAX_SEG) * MVK_NOALLOC_MAX_STATES * sizeof(uint32_t);
+constexpr size_t kStaticRecordBytes = static_cast<size_t>(MVK_NOALLOC_MAX_STATES) * (8 + 2 * MVK_MAX_JOINT) * sizeof(double);
+constexpr size_t kStaticScratchBytes = 2 * kStaticCounterSetBytes + kStaticQueueBytes + kStaticRecordBytes;  // 22.1 MiB
+// address of the calling thread's current device's copy of that array (resolved once per device with
+// hipGetSymbolAddress, mvk_kernels.hip); returns hipError_t as int
+int static_scratch_for_current_device(int device, void** ptr);
+
 // launchers implemented in mvk_kernels.hip; return hipError_t as int
 // events: nullptr, or hipEvent_t[3] recorded before / between / after the kernels of the call
 int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream, void* events);

@@ -25,11 +25,46 @@
 
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 #include "mvk_internal.h"
 
 namespace mvk {
+
+// ------------------------------------------------------------------------
+// scratch of the no-allocation entry point (mvk_is_valid_mask_noalloc_dev)
+// ------------------------------------------------------------------------
+// Callers that cannot allocate (code under HIP graph capture, tight serving loops) get the flag path with its
+// hand-off queues, records and counters in this file-scope array instead of ctx-owned hipMalloc memory.  Each
+// GPU the library runs on holds its own copy (22.1 MiB) at its own address until the process ends.  In host code
+// the NAME `scratch` is only a handle for the runtime, not a device address: the address of the current device's
+// copy comes from hipGetSymbolAddress, once per device, and only that pointer is ever handed to kernels and
+// memsets.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+int static_scratch_for_current_device(int device, void** ptr) {
+  constexpr int kMaxDevices = 64;
+  static void* resolved[kMaxDevices] = {};
+  static std::mutex guard;
+  *ptr = nullptr;
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lk(guard);
+  if (!resolved[device]) {
+    int current = -1;
+    hipError_t e = hipGetDevice(&current);
+    if (e != hipSuccess) return e;
+    if (current != device) return hipErrorInvalidDevice;  // the caller makes `device` current first
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    resolved[device] = p;
+  }
+  *ptr = resolved[device];
+  return hipSuccess;
+}
+
 namespace {
 
 // ------------------------------------------------------------------------

@@ -317,6 +317,15 @@ class Engine:
         _check(self.lib, self.lib.mvk_is_valid_mask_dev(self.ctx, self._dp(d_soa), n, ld, layout, self._dp(d_mask),
                                                         self._stream(stream)))
 
+    def is_valid_mask_noalloc_dev(self, d_soa, layout, d_mask, stream=None):
+        """mvk_is_valid_mask_dev for callers that cannot allocate (at most A.NOALLOC_MAX_STATES states per call)"""
+        rows, n = d_soa.shape
+        ld = d_soa.stride(0)
+        assert d_soa.stride(1) == 1 and rows == self.state_dim(layout)
+        assert d_mask.numel() * 64 >= n
+        _check(self.lib, self.lib.mvk_is_valid_mask_noalloc_dev(self.ctx, self._dp(d_soa), n, ld, layout, self._dp(d_mask),
+                                                                self._stream(stream)))
+
     def sweep_mask_dev(self, root_pose7, first_index, n, seed, d_mask, stream=None):
         """C-space sweep: states generated in the kernel from the sample index (include/mvk.h)."""
         pose = np.ascontiguousarray(root_pose7, np.float64)
