@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- state validity checks/sec on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the batched validity predicate over one resident batch:
-config c2 of BASELINE.json (HYDRUS 6-link, joints+base, 1,048,576 random samples,
-100 box obstacles), inputs already in HBM, flags written as a packed bit mask.
+One "step" = one pass of the batched validity predicate over one resident batch of
+the north star's target workload "c2k": HYDRUS 6-link, joints+base, 1,048,576 random
+samples, 1000 box obstacles (FK + statics + collision), inputs already in HBM, flags
+written as a packed bit mask.  The other single-GPU configurations of BASELINE.json
+(c2: 100 boxes, c3: DRAGON + 1000 boxes, c5: HYDRUS 8-link C-space sweep) are timed
+as legs of the same line ("workloads"), c4 as "edge_checks".
 With N > 1 GPUs (one process per GPU, torch.distributed over RCCL) every rank
 checks its own 1M-sample shard (weak scaling) and each step ends with the
 all-gather of the packed masks + all-reduce of the valid count, the only
@@ -26,8 +29,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # algorithmic work per check
 F_MODEL = {("hydrus", 4): 2.4e3, ("hydrus", 6): 5.6e3, ("hydrus", 8): 11.3e3, ("dragon", 4): 4.7e3}
 F_PAIR = 30.0
-PEAK_FP64_VALU_TFLOPS = 78.6   # MI355X datasheet fp64 vector peak
+PEAK_FP64_VALU_TFLOPS = 78.6   # MI355X datasheet fp64 vector peak = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# VALU issue peak: a wave64 VALU instruction occupies its SIMD's 16 lanes for 4 cycles
+# (256 CUs x 4 SIMDs x 2.4 GHz / 4 = 6.144e11 wave instructions / s); an fp64 FMA is one such instruction
+PEAK_VALU_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4
 
 
 def cpu_baseline(w, budget_s=12.0):
@@ -155,6 +161,98 @@ def distance_path(eng, w, d_soa, dev):
                                "outputs": "per primitive: distance, nearest box and points, constraint row, bound"}}
 
 
+def make_workload(name, n):
+    import common
+    if name == "c2":
+        return common.config2(n=n)
+    if name == "c2se3":
+        return common.config2(n=n, orient="so3")
+    if name == "c2k":
+        return common.config2k(n=n)
+    if name == "c3":
+        return common.config3(n=n)
+    return common.config5(n=64)   # c5: the sweep generates its states in the kernel, only model / scene / params are used
+
+
+def roofline_of(workload, w, n, screen_ms, exact_ms, call_ms, sweep):
+    """roofline object of the dominant kernel (screen_kernel) of one flag-path launch over n states.
+
+    The path is VALU bound (no dense contraction, ~100 B of HBM traffic per check), so `bound`
+    deviates from the hbm|mfma menu on purpose.  frac = executed VALU wave instructions per launch (SQ_INSTS_VALU of
+    the committed rocprofv3 PMC pass of this workload, profiles/latest_pmc.json) / the kernel's duration measured
+    live / the chip's VALU issue peak: a number <= 1.  `achieved` is the same rate in TFLOP/s, every executed
+    instruction counted as an fp64 FMA on 64 lanes (128 flop), against the fp64 vector peak.  The all-pairs model of
+    SURVEY.md 8(d) (n * (F_model + P*M*30) flop, most of which the broadphase grid never executes) is reported as
+    cull_gain_vs_allpairs; it is not a utilisation."""
+    kind = "dragon" if w.model.has_gimbal else "hydrus"
+    NL, P, M, J = w.model.n_rotor, w.model.n_prim, len(w.boxes), w.model.n_joint
+    f_model = F_MODEL[(kind, NL)]
+    f_alg = f_model + P * M * F_PAIR
+    b_alg = (0 if sweep else 8 * (7 + J)) + 1.0 / 8.0
+    t = screen_ms * 1e-3
+    pmc = pmc_traffic(workload) or {}
+    insts = pmc.get("valu_insts_per_launch")
+    scale = n / pmc["states_per_launch"] if insts and pmc.get("states_per_launch") else 1.0
+    rate = insts * scale / t if insts else None
+    return {"bound": "valu_fp64", "kernel": "screen_kernel",
+            "achieved": rate * 128.0 / 1e12 if rate else None, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": rate / PEAK_VALU_WAVE_INSTS_PER_S if rate else None,
+            "frac_definition": "executed VALU wave instructions per launch (PMC SQ_INSTS_VALU) / kernel_ms / 6.144e11 per s",
+            "valu_wave_insts_per_launch": insts * scale if insts else None,
+            "valu_busy_pmc": pmc.get("valu_busy"),
+            "traffic": pmc.get("hbm_bytes_per_launch"),
+            "kernel_ms": screen_ms, "second_kernel": "exact_kernel", "second_kernel_ms": exact_ms, "call_ms": call_ms,
+            "bytes_per_check": b_alg, "flop_per_check_uncullable": f_model, "flop_per_check_allpairs": f_alg,
+            "achieved_uncullable_tflops": n * f_model / t / 1e12,
+            "cull_gain_vs_allpairs": n * f_alg / t / 1e12 / PEAK_FP64_VALU_TFLOPS,
+            "hbm": {"achieved": n * b_alg / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": n * b_alg / t / 1e9 / PEAK_HBM_GBS},
+            "pmc_source": pmc.get("source")}
+
+
+def workload_leg(name, n, dev, steps=10, warmup=2):
+    """one more single-GPU configuration of BASELINE.json through the same flag path: ms per step over `steps` launches
+    (torch events on the launch stream), the per-kernel split, and its own roofline object"""
+    import torch
+
+    import common
+    import motion_planning_amd as mp
+    w = make_workload(name, n)
+    sweep = name == "c5"
+    eng = mp.Engine(w.model, w.boxes, w.params, device=dev.index)
+    eng.set_profiling(True)
+    d_soa = torch.from_numpy(w.soa).to(dev)
+    mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+    pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
+
+    def run():
+        if sweep:
+            eng.sweep_mask_dev(pose, 0, n, common.SEED0 + 5, mask)
+        else:
+            eng.is_valid_mask_dev(d_soa, w.layout, mask)
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    split = []
+    for _ in range(5):
+        run()
+        split.append(eng.last_kernel_ms())
+    screen_ms, exact_ms = float(np.mean([x[0] for x in split])), float(np.mean([x[1] for x in split]))
+    bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")[:n]
+    eng.close()
+    kind = "dragon" if w.model.has_gimbal else "hydrus"
+    return {"workload": f"{name}: {kind.upper()} {w.model.n_rotor}-link, {n} samples, {len(w.boxes)} box obstacles"
+                        + (", states generated in-kernel (C-space sweep)" if sweep else ""),
+            "ms_per_step": ms, "checks_per_s": n / ms * 1e3, "steps": steps, "valid_fraction": float(bits.mean()),
+            "roofline": roofline_of(name, w, n, screen_ms, exact_ms, ms, sweep)}
+
+
 def pmc_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/latest_pmc.json, written by profiles/summarize.py; FETCH_SIZE already doubled per the
@@ -228,7 +326,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=1 << 20)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2se3", "c2k", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2k", choices=["c2", "c2se3", "c2k", "c3", "c4", "c5"],
+                    help="headline workload (default: the north star's target, 6-link HYDRUS with 1k obstacles)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the other single-GPU workloads (c2, c3, c5)")
     ap.add_argument("--edges", type=int, default=1 << 16, help="c4: edges per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-planner", action="store_true")
@@ -261,16 +361,7 @@ def main():
     if args.workload == "c4":
         return bench_edges(args, world, rank, local_rank, dev)
     n = args.samples
-    if args.workload == "c2":
-        w = common.config2(n=n)
-    elif args.workload == "c2se3":
-        w = common.config2(n=n, orient="so3")
-    elif args.workload == "c2k":
-        w = common.config2k(n=n)
-    elif args.workload == "c3":
-        w = common.config3(n=n)
-    else:
-        w = common.config5(n=64)   # the sweep generates its states in the kernel: only model / scene / params are used
+    w = make_workload(args.workload, n)
     kind = "dragon" if w.model.has_gimbal else "hydrus"
     NL, P, M, J = w.model.n_rotor, w.model.n_prim, len(w.boxes), w.model.n_joint
     if world > 1 and args.workload != "c5":
@@ -364,11 +455,6 @@ def main():
         valid = int(sum(bin(int(x) & 0xFFFFFFFFFFFFFFFF).count("1") for x in d_mask.cpu().numpy()[:4096]))
         total = world * n * args.steps
         value = total / elapsed
-        f_model = F_MODEL[(kind, NL)]
-        f_alg = f_model + P * M * F_PAIR
-        b_alg = (0 if sweep else 8 * (7 + J)) + 1.0 / 8.0
-        ach_tflops = n * f_alg / (screen_ms * 1e-3) / 1e12
-        pmc = pmc_traffic(args.workload)
         out = {
             "metric": "state validity checks/sec",
             "value": value,
@@ -385,21 +471,8 @@ def main():
             "config": {"workload": f"{w.name}: {kind.upper()} {NL}-link, joints+base, {n} samples/GPU, {M} box obstacles, "
                                    f"{P} robot primitives, flags as packed mask" + (", states generated in-kernel (C-space sweep)" if sweep else ""),
                        "samples_per_gpu": n, "obstacles": M, "links": NL, "parallelism": f"shard{world}"},
-            # the path is fp64-VALU bound (no dense contraction, ~100 B of HBM traffic per check), so
-            # `bound` deviates from the hbm|mfma menu on purpose.  achieved = n * F_alg / t(screen_kernel), with
-            # F_alg = F_model + P*M*30 the all-pairs model: the broadphase grid skips most pairs, so frac > 1 means
-            # "the cull beat brute force"; achieved_uncullable counts only the model update every check must do.
-            "roofline": {"bound": "valu_fp64", "kernel": "screen_kernel", "achieved": ach_tflops,
-                         "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP64_VALU_TFLOPS,
-                         "traffic": (pmc or {}).get("hbm_bytes_per_launch"),
-                         "kernel_ms": screen_ms, "second_kernel": "exact_kernel", "second_kernel_ms": exact_ms,
-                         "call_ms": call_ms,
-                         "flop_per_check": f_alg, "flop_per_check_uncullable": f_model, "bytes_per_check": b_alg,
-                         "achieved_uncullable": n * f_model / (screen_ms * 1e-3) / 1e12,
-                         "valu_busy_pmc": (pmc or {}).get("valu_busy"),
-                         "hbm": {"achieved": n * b_alg / (screen_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": n * b_alg / (screen_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
-                         "pmc_source": (pmc or {}).get("source")},
+            "roofline": roofline_of(args.workload, w, n, screen_ms, exact_ms, call_ms, sweep),
+            "rccl_ranks": dist.get_world_size() if exchange else 1,
             "valid_in_first_4096_words": valid,
         }
         if exchange:
@@ -412,6 +485,8 @@ def main():
             out["rrt_connect"] = rrt_connect_gap_pass()
         if not args.no_edges and world == 1:
             out["edge_checks"] = edge_checks(dev)
+        if not args.no_legs and world == 1:
+            out["workloads"] = {k: workload_leg(k, n, dev) for k in ("c2", "c3", "c5") if k != args.workload}
         if not args.no_distance and world == 1 and not sweep:
             out["distance_path"] = distance_path(eng, w, d_soa, dev)
         print(json.dumps(out))

@@ -8,6 +8,9 @@ written into the json that bench.py reads for its roofline object:
                           wide streaming read, MI355X_MICROARCH.md "HBM"; both counters are in KiB)
   valu_busy            = 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 * 1024)
                          (quad-cycles summed over the chip vs cycles of one XCD times the 1024 SIMDs)
+  valu_insts_per_launch = SQ_INSTS_VALU (wave instructions executed by one launch, summed over the chip) and
+  states_per_launch     = 64 * SQ_WAVES: bench.py divides the former by the kernel's live duration and by the VALU
+                         issue peak (1024 SIMDs x 2.4 GHz / 4) for roofline.frac
 """
 import csv
 import glob
@@ -50,6 +53,9 @@ def main():
             except (OSError, ValueError):
                 d = {}
             d[opt.get("workload", "c2")] = {"kernel": kn, "hbm_bytes_per_launch": hbm, "valu_busy": busy,
+                                           "valu_insts_per_launch": mean[(kn, "SQ_INSTS_VALU")],
+                                           "states_per_launch": mean[(kn, "SQ_WAVES")] * 64.0,
+                                           "wait_any_frac": mean.get((kn, "SQ_WAIT_ANY"), 0.0) / mean[(kn, "SQ_WAVE_CYCLES")] if (kn, "SQ_WAVE_CYCLES") in mean else None,
                                            "source": opt.get("source", os.path.basename(out.rstrip("/")))}
             json.dump(d, open(opt["merge"], "w"), indent=1, sort_keys=True)
 
