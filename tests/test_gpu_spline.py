@@ -28,3 +28,21 @@ def test_device_spline_evaluation_matches_host(degree, J, nt):
     with pytest.raises(mp.MvkError):
         sp.eval_dev(d_t, degree)
     sp.close()
+
+
+@pytest.mark.parametrize("degree", [5, 3])
+def test_device_spline_evaluation_matches_the_scipy_golden_vectors(degree):
+    """tests/golden/spline_d*.npz: scipy.interpolate.BSpline values (made by tests/golden/make_spline_golden.py)"""
+    import os
+
+    import torch
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"spline_d{degree}.npz"))
+    sp = PP.Spline(g["path"], float(g["period"]), int(g["degree"]))
+    d_t = torch.from_numpy(g["t"]).cuda()
+    nc = len(g["path"]) + 2
+    for k in range(3):
+        got = sp.eval_dev(d_t, k).cpu().numpy().T
+        ref = g[f"d{k}"]
+        tol = 1e-10 if k == 0 else 1e-8 * max(1.0, (nc / float(g["period"])) ** k) + 1e-8 * np.abs(ref).max()
+        assert np.allclose(got, ref, rtol=0, atol=tol), (k, np.abs(got - ref).max())
+    sp.close()

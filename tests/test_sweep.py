@@ -8,6 +8,7 @@ import pytest
 
 import common
 import motion_planning_amd as mp
+import oracle_lib as O
 from motion_planning_amd import _abi as A
 
 
@@ -86,4 +87,8 @@ def test_device_sweep_matches_materialised_states():
         eng.mask_count_dev(mask, n, cnt)       # the scalar all-reduced next to the mask gather
         assert int(cnt.item()) == int(ref.sum())
         assert 0 < ref.sum() < n or n < 100
+        # not only device vs device: a slice of the sweep against the oracle on the materialised states
+        k = min(n, 4096)
+        o = O.eval_batch(w.model, w.boxes, w.params, st[:, :k], A.LAYOUT_POSE7, threads=8)
+        assert not np.any((bits[:k] != o["flags"]) & ~o["band"].astype(bool)), (first, n)
     eng.close()
