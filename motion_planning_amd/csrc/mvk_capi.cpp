@@ -133,7 +133,7 @@ struct mvk_ctx {
   Buf edge_blob;
   PinBuf pin_up, pin_down;
   // statistics of the last FULL batch
-  Buf partial, stats_out;
+  Buf partial, stats_out, full_rec;
   uint64_t last_blocks = 0, last_n = 0;
   bool stats_valid = false;
 };
@@ -512,6 +512,12 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
     a.stats_partial = c->partial.p;
     c->last_blocks = blocks;
     c->last_n = n;
+    if (a.do_coll && a.n_obs > 0) {  // the distance kernel follows: hand-off rows for every launched lane
+      const uint64_t rec_ld = blocks * kBlock;
+      if (int rc = c->full_rec.reserve((2 * static_cast<uint64_t>(c->model.n_joint) + 5) * rec_ld * sizeof(double))) return rc;
+      a.full_rec = static_cast<double*>(c->full_rec.p);
+      a.full_rec_ld = rec_ld;
+    }
   } else if (int rc = prepare_queue(c, a, n)) {
     return rc;
   }
@@ -646,7 +652,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
   if (c->d_extras) (void)hipFree(c->d_extras);
   Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start[0], &c->dgrid_items[0], &c->dgrid_start[1], &c->dgrid_items[1], &c->queue, &c->queue_rec, &c->queue_counts, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
-                &c->partial, &c->stats_out, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
+                &c->partial, &c->stats_out, &c->full_rec, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
   for (Buf* b : all) b->release();
   c->edge_blob.release();
   c->pin_up.release();

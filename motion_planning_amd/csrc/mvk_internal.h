@@ -135,6 +135,10 @@ struct EvalArgs {
   uint32_t exact_blocks;       // grid of the exact stage
   // per-block partial statistics (full mode) or nullptr
   void* stats_partial;
+  // full path hand-off from model_kernel to distance_kernel (ctx-owned; nullptr: no collision stage, the model
+  // kernel finishes the states itself): rows of full_rec_ld doubles -- cos/sin of every joint, then five scalars
+  double* full_rec;
+  uint64_t full_rec_ld;
   // C-space sweep (mvk_sweep_mask_dev): states are generated from the sample index, nothing is read
   int32_t sweep_on;
   uint64_t sweep_first, sweep_seed;

@@ -474,6 +474,10 @@ struct Smem {
   lds_uint* ex_win;
   // full path: per primitive (first kUpperSlots of the chain order) the first walk's upper bound, [kUpperSlots][kBlock]
   lds_float* upper;
+  // full path, distance kernel: the joints' cos/sin rows left in HBM by the model kernel, [2*J][gcs_ld] (row pitch in
+  // doubles), this lane's column gcs_col; nullptr: they are in `cs` (LDS)
+  const double* gcs;
+  uint64_t gcs_ld, gcs_col;
 };
 constexpr int kUpperSlots = 16;
 constexpr int kExactBatch = 16;  // box pairs whose exact distance one wave computes together
@@ -794,7 +798,14 @@ DEV void advance_frame(const mvk_model* __restrict__ M, const Smem& sm, int src,
   xform(R, p, M->seg_t[k][0], M->seg_t[k][1], M->seg_t[k][2], pn);
   p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
   const int jn = M->seg_joint[k];
-  const double c = sm.cs[(2 * jn) * kBlock + src], s = sm.cs[(2 * jn + 1) * kBlock + src];
+  double c, s;
+  if (sm.gcs) {  // (wave-uniform) coalesced row reads: lane-contiguous columns
+    c = sm.gcs[static_cast<uint64_t>(2 * jn) * sm.gcs_ld + sm.gcs_col];
+    s = sm.gcs[static_cast<uint64_t>(2 * jn + 1) * sm.gcs_ld + sm.gcs_col];
+  } else {
+    c = sm.cs[(2 * jn) * kBlock + src];
+    s = sm.cs[(2 * jn + 1) * kBlock + src];
+  }
   rot_cols_dyn(R, M->seg_axis[k], c, s);
 }
 
@@ -2191,47 +2202,21 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 #endif
 }
 
-// Two waves per SIMD on purpose: left alone the compiler takes 256 VGPRs + 50 AGPRs, one wave per SIMD, and
-// every dependent gather of the distance walk (cell -> ids -> boxes) is exposed.  Fitting 256 registers costs
-// 40-110 spilled VGPRs and still runs 1.4-1.5x faster; three waves spill 140-240 and gain nothing more.
-template <int ROBOT, int NL>
-__global__ void __launch_bounds__(kBlock, 2)
-full_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
-            const DevObs* __restrict__ obs) {
-  using S = Shape<ROBOT, NL>;
-  constexpr int NJ = S::kJoint;
-  __shared__ double sm_cs[2 * NJ * kBlock];
-  __shared__ unsigned short sm_list[kListCap * kBlock];
-  __shared__ double sm_ex_item[(kBlock / 64) * kExactBatch * kExactItem];
-  __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kExactBatch];
-  __shared__ float sm_upper[kUpperSlots * kBlock];
-  Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list, (lds_double*)sm_ex_item + (threadIdx.x >> 6) * kExactBatch * kExactItem,
-          (lds_u64*)sm_ex_res + (threadIdx.x >> 6) * kExactBatch, nullptr, nullptr, (lds_float*)sm_upper};
+// Full path = two launches on one stream: the statics want registers and have no gathers, the distance
+// walks are chains of dependent gathers (cell -> ids -> boxes) and want occupancy, so each gets its own kernel.
+//   model_kernel    : walk 1 in full (FK, CoG, statics, feasible-control distances, margins, details).  With the
+//                     collision stage on it leaves, per state, the joints' cos/sin rows and the five scalars the
+//                     verdict and the statistics need (FullRec rows, lane-contiguous: coalesced both ways);
+//                     without it (mode 0, empty world) it writes the verdicts itself.
+//   distance_kernel : the two grid walks and the narrowphase drain (collide_full), then verdict, band, statistics.
+// Rows of the hand-off, each [ld] doubles: cos/sin of joint j at 2j / 2j+1, then
+constexpr int kFullRecMargin = 0, kFullRecLamMin = 1, kFullRecLamMax = 2, kFullRecRp = 3, kFullRecFinite = 4, kFullRecScalars = 5;
 
-  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  const bool in_range = gi < A.n;
-  const uint64_t li = in_range ? gi : (A.n - 1);
-
-  double st[7 + NJ];
-  uint64_t edge;
-  int step;
-  fetch_state<NJ, false, true>(A, li, st, edge, step);
-
+// verdict, band, per-state outputs and the block's partial statistics (motion_planning.cpp:615-632 extrema)
+DEV void full_finish(const EvalArgs& A, uint64_t gi, bool in_range, bool finite, double margin, double lam_min, double lam_max,
+                     double rp_margin, double mind, bool stable) {
   StateOut o;
-  double thrust[NL];
-  double Rw[9];
-  bool finite;
-  PROF_ACC_DECL;
-  PROF_T0(t_mu);
-  model_update<ROBOT, NL, true>(A, M, X, st, sm, li, o, Rw, finite, thrust);
-  PROF_CLK(4, t_mu);
-
-  double mind = INFINITY;
-  PROF_T0(t_cf);
-  if (A.do_coll && A.n_obs > 0 && __any(finite)) mind = collide_full<ROBOT, NL>(A, M, X, obs, st, Rw, sm, finite);
-  PROF_CLK(5, t_cf);
-  PROF_ACC_FLUSH(20);
-  PROF_WAVE(28);
+  o.margin = margin; o.lam_min = lam_min; o.lam_max = lam_max; o.rp_margin = rp_margin; o.stable = stable;
   o.min_dist = (A.do_coll && finite) ? mind : INFINITY;
   o.collision = A.do_coll && (mind <= 0.0);
   o.valid = finite && (!A.do_stab || o.stable) && !o.collision;
@@ -2243,20 +2228,12 @@ full_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* 
     if (A.band) A.band[gi] = o.band ? 1 : 0;
     if (A.min_dist) A.min_dist[gi] = o.min_dist;
     if (A.margin) A.margin[gi] = o.margin;
-    if (A.fc_t_min) A.fc_t_min[gi] = o.fc_t_min;
-    if (A.fc_rp_min) A.fc_rp_min[gi] = o.fc_rp_min;
-    if (A.rp_margin) A.rp_margin[gi] = o.rp_margin;
-    if (A.thrust) {
-#pragma unroll
-      for (int i = 0; i < NL; ++i) A.thrust[i * A.ld + gi] = thrust[i];
-    }
   }
   if (A.mask) {
     const unsigned long long bal = __ballot(in_range && o.valid);
     if ((threadIdx.x & 63) == 0 && (gi - (gi & 63)) < A.n) A.mask[gi >> 6] = bal;
   }
 
-  // ---- per-block statistics (FULL batches): motion_planning.cpp:615-632 extrema ---
   if (A.stats_partial) {
     __shared__ StatsPartial sm_part[kBlock / 64];
     StatsPartial mine;
@@ -2306,6 +2283,94 @@ full_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* 
       static_cast<StatsPartial*>(A.stats_partial)[blockIdx.x] = acc;
     }
   }
+}
+
+template <int ROBOT, int NL>
+__global__ void __launch_bounds__(kBlock, 2)
+model_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ double sm_cs[2 * NJ * kBlock];
+  Smem sm{(lds_double*)sm_cs, nullptr};
+
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, false, true>(A, li, st, edge, step);
+
+  StateOut o;
+  double thrust[NL];
+  double Rw[9];
+  bool finite;
+  model_update<ROBOT, NL, true>(A, M, X, st, sm, li, o, Rw, finite, thrust);
+
+  if (in_range) {
+    if (A.fc_t_min) A.fc_t_min[gi] = o.fc_t_min;
+    if (A.fc_rp_min) A.fc_rp_min[gi] = o.fc_rp_min;
+    if (A.rp_margin) A.rp_margin[gi] = o.rp_margin;
+    if (A.thrust) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) A.thrust[i * A.ld + gi] = thrust[i];
+    }
+  }
+  if (A.full_rec) {  // the collision stage follows in distance_kernel
+    double* __restrict__ rec = A.full_rec;
+#pragma unroll
+    for (int r = 0; r < 2 * NJ; ++r) rec[static_cast<uint64_t>(r) * A.full_rec_ld + gi] = sm.cs[r * kBlock + threadIdx.x];
+    double* __restrict__ sc = rec + static_cast<uint64_t>(2 * NJ) * A.full_rec_ld;
+    sc[static_cast<uint64_t>(kFullRecMargin) * A.full_rec_ld + gi] = o.margin;
+    sc[static_cast<uint64_t>(kFullRecLamMin) * A.full_rec_ld + gi] = o.lam_min;
+    sc[static_cast<uint64_t>(kFullRecLamMax) * A.full_rec_ld + gi] = o.lam_max;
+    sc[static_cast<uint64_t>(kFullRecRp) * A.full_rec_ld + gi] = o.rp_margin;
+    sc[static_cast<uint64_t>(kFullRecFinite) * A.full_rec_ld + gi] = finite ? 1.0 : 0.0;
+    return;
+  }
+  full_finish(A, gi, in_range, finite, o.margin, o.lam_min, o.lam_max, o.rp_margin, INFINITY, o.stable);
+}
+
+// Occupancy over registers: the walks wait on dependent gathers, so the kernel is compiled for kDistanceWaves waves
+// per SIMD and its LDS (candidate lists, first-walk bounds, the wave's exact-distance batch) is sized to allow them.
+#ifndef MVK_DISTANCE_WAVES
+#define MVK_DISTANCE_WAVES 3
+#endif
+constexpr int kDistanceWaves = MVK_DISTANCE_WAVES;
+template <int ROBOT, int NL>
+__global__ void __launch_bounds__(kBlock, kDistanceWaves)
+distance_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                const DevObs* __restrict__ obs) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ unsigned short sm_list[kListCap * kBlock];
+  __shared__ double sm_ex_item[(kBlock / 64) * kExactBatch * kExactItem];
+  __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kExactBatch];
+  __shared__ float sm_upper[kUpperSlots * kBlock];
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+  Smem sm{nullptr, (lds_ushort*)sm_list, (lds_double*)sm_ex_item + (threadIdx.x >> 6) * kExactBatch * kExactItem,
+          (lds_u64*)sm_ex_res + (threadIdx.x >> 6) * kExactBatch, nullptr, nullptr, (lds_float*)sm_upper,
+          A.full_rec, A.full_rec_ld, gi};   // (the record rows are written for every launched lane: gi, not li)
+
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, false, false>(A, li, st, edge, step);  // the root pose; the joints come as cos/sin rows
+  double Rw[9];
+  quat_to_mat(st[3], st[4], st[5], st[6], Rw);
+  const double* __restrict__ sc = A.full_rec + static_cast<uint64_t>(2 * NJ) * A.full_rec_ld;
+  const bool finite = sc[static_cast<uint64_t>(kFullRecFinite) * A.full_rec_ld + gi] != 0.0;
+
+  double mind = INFINITY;
+  if (__any(finite)) mind = collide_full<ROBOT, NL>(A, M, X, obs, st, Rw, sm, finite);
+
+  const double margin = sc[static_cast<uint64_t>(kFullRecMargin) * A.full_rec_ld + gi];
+  full_finish(A, gi, in_range, finite, margin, sc[static_cast<uint64_t>(kFullRecLamMin) * A.full_rec_ld + gi],
+              sc[static_cast<uint64_t>(kFullRecLamMax) * A.full_rec_ld + gi], sc[static_cast<uint64_t>(kFullRecRp) * A.full_rec_ld + gi],
+              mind, margin >= 0.0);
 }
 
 
@@ -2717,8 +2782,10 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s, hipEvent_t* e
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
   if (ev) (void)hipEventRecord(ev[0], s);
   if (a.full && !edge_mode) {
-    hipLaunchKernelGGL((full_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras, a.obs);
-    if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
+    hipLaunchKernelGGL((model_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras);
+    if (ev) (void)hipEventRecord(ev[1], s);
+    if (a.full_rec) hipLaunchKernelGGL((distance_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras, a.obs);
+    if (ev) (void)hipEventRecord(ev[2], s);
     return hipGetLastError();
   }
   // exact stage: as many blocks as the chip holds at once stride over the chunks of all queues

@@ -38,5 +38,5 @@ for name in sys.argv[1:] or ["c2", "c2k", "c3", "c5"]:
         eng.collision_avoidance_batch_dev(da, w.layout, outs)
         torch.cuda.synchronize()
         ta.append(time.perf_counter() - t0)
-    print(f"{name}: full_kernel {t[:, 0].mean():.2f} ms per 1M; avoidance rows {1e3 * min(ta[1:]):.2f} ms per 256k; min_dist > 0.3: {(m > 0.3).mean():.3f}, > 0.5: {(m > 0.5).mean():.3f}, > 1.0: {(m > 1.0).mean():.3f}", flush=True)
+    print(f"{name}: model_kernel {t[:, 0].mean():.3f} + distance_kernel {t[:, 1].mean():.3f} ms per 1M; avoidance rows {1e3 * min(ta[1:]):.2f} ms per 256k; min_dist > 0.3: {(m > 0.3).mean():.3f}, > 0.5: {(m > 0.5).mean():.3f}, > 1.0: {(m > 1.0).mean():.3f}", flush=True)
     eng.close()
