@@ -253,6 +253,46 @@ def workload_leg(name, n, dev, steps=10, warmup=2):
             "roofline": roofline_of(name, w, n, screen_ms, exact_ms, ms, sweep)}
 
 
+def fp32_variant(eng, w, d_soa, n, dev, steps=10):
+    """BASELINE.json north_star: "fp32 variant reported with its own tolerance".  The same batch through
+    MVK_PRECISION_F32_REFINED (model update, stability tests and the collision screen's frames in fp32 with error
+    bounds; verdicts the bounds cannot guarantee, and every possible contact, are taken again in fp64) next to the
+    fp64 flag path: rate, share of states refined, and the number of verdicts that differ."""
+    import torch
+    from motion_planning_amd import _abi as A
+    words = (n + 63) // 64
+    m64 = torch.zeros(words, dtype=torch.int64, device=dev)
+    m32 = torch.zeros(words, dtype=torch.int64, device=dev)
+    band = torch.zeros(n, dtype=torch.uint8, device=dev)
+    fl = torch.zeros(n, dtype=torch.uint8, device=dev)
+    eng.is_valid_mask_dev(d_soa, w.layout, m64)
+    eng.is_valid_batch_dev(d_soa, w.layout, d_flags=fl, d_band=band)     # the full path's boundary band (1e-6)
+    eng.set_flag_precision(A.PRECISION_F32_REFINED)
+    for _ in range(2):
+        eng.is_valid_mask_dev(d_soa, w.layout, m32)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        eng.is_valid_mask_dev(d_soa, w.layout, m32)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    split = eng.last_kernel_ms()
+    refined = eng.last_refined_count()
+    eng.set_flag_precision(A.PRECISION_F64)
+    b64 = np.unpackbits(m64.cpu().numpy().view(np.uint8), bitorder="little")[:n]
+    b32 = np.unpackbits(m32.cpu().numpy().view(np.uint8), bitorder="little")[:n]
+    diff = b64 != b32
+    inb = band.cpu().numpy().astype(bool)
+    return {"dtype": "f32 screen stage, uncertain verdicts and possible contacts refined in f64",
+            "ms_per_step": ms, "checks_per_s": n / ms * 1e3, "screen_stage_ms": split[0], "exact_stage_ms": split[1],
+            "refined_fraction": refined / n,
+            "tolerance": "fp32 stage: slack errors bounded per test by first-order propagation (~1e-4 relative), frame "
+                         "positions by <= 1e-3 m; no verdict is taken within those bounds, so flags carry the fp64 path's 1e-6 band only",
+            "mismatches_vs_f64_flag_path": int(diff.sum()), "mismatches_outside_band": int((diff & ~inb).sum())}
+
+
 def pmc_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/latest_pmc.json, written by profiles/summarize.py; FETCH_SIZE already doubled per the
@@ -328,6 +368,7 @@ def main():
     ap.add_argument("--samples", type=int, default=1 << 20)
     ap.add_argument("--workload", default="c2k", choices=["c2", "c2se3", "c2k", "c3", "c4", "c5"],
                     help="headline workload (default: the north star's target, 6-link HYDRUS with 1k obstacles)")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-variant leg")
     ap.add_argument("--no-legs", action="store_true", help="skip the other single-GPU workloads (c2, c3, c5)")
     ap.add_argument("--edges", type=int, default=1 << 16, help="c4: edges per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -489,6 +530,8 @@ def main():
             out["workloads"] = {k: workload_leg(k, n, dev) for k in ("c2", "c3", "c5") if k != args.workload}
         if not args.no_distance and world == 1 and not sweep:
             out["distance_path"] = distance_path(eng, w, d_soa, dev)
+        if not args.no_fp32 and world == 1 and not sweep:
+            out["fp32_variant"] = fp32_variant(eng, w, d_soa, n, dev)
         print(json.dumps(out))
     eng.close()
     if exchange:

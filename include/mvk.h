@@ -237,6 +237,22 @@ void mvk_destroy(mvk_ctx* ctx);
 int mvk_set_scene(mvk_ctx* ctx, const mvk_box* boxes, size_t n_boxes);
 int mvk_set_params(mvk_ctx* ctx, const mvk_params* params);
 int mvk_get_params(const mvk_ctx* ctx, mvk_params* out);
+/* Arithmetic of the flag path (the entry points that return verdicts only: mvk_is_valid_batch[_dev] without
+ * distance / margin / band outputs, mvk_is_valid_mask_dev, mvk_sweep_mask_dev, mvk_check_motion_batch*).
+ * The reference computes everything in fp64 (motion_planning.cpp:76-164 over KDL / Eigen / FCL doubles), and so
+ * does MVK_PRECISION_F64, the default.  MVK_PRECISION_F32_REFINED is the fp32 variant BASELINE.json's north star
+ * asks for: the model update, the stability tests and the frames of the collision screen run in fp32 with
+ * first-order bounds on their evaluation errors; a verdict is taken in fp32 only where the bounds leave no
+ * doubt, every other state (and every possible contact, as always) is evaluated again in fp64.  The flags are
+ * therefore the SAME as with MVK_PRECISION_F64 outside the 1e-6 boundary band (tests/test_gpu_f32.py); tolerance
+ * of the fp32 stage itself: slack errors bounded by ~1e-4 relative, positions by 1e-3 m.
+ * Distances, margins and details are always fp64 (full path). */
+enum { MVK_PRECISION_F64 = 0, MVK_PRECISION_F32_REFINED = 1 };
+int mvk_set_flag_precision(mvk_ctx* ctx, int precision);
+/* number of states the last MVK_PRECISION_F32_REFINED call on this ctx handed to the fp64 screen (waits for that
+ * call; measurement only, like mvk_last_kernel_ms) */
+int mvk_last_refined_count(mvk_ctx* ctx, uint64_t* out);
+
 /* Kernel timing for benchmarks (no counterpart in the reference, which only times the whole
  * solve: motion_planning.cpp:406-410).  When enabled, every batched call records HIP events on
  * its launch stream around its kernels; mvk_last_kernel_ms waits for the last call and returns

@@ -17,6 +17,7 @@ PRIM_SPHERE, PRIM_CAPSULE, PRIM_BOX = 0, 1, 2
 FRAME_SEG, FRAME_GIMBAL_ROLL, FRAME_GIMBAL_PITCH = 0, 1, 2
 LAYOUT_POSE7, LAYOUT_OMPL = 0, 1
 NOALLOC_MAX_STATES = 65536
+PRECISION_F64, PRECISION_F32_REFINED = 0, 1
 
 d, i32 = C.c_double, C.c_int32
 
@@ -129,6 +130,8 @@ PROTOTYPES = {
     "mvk_set_scene": (ip, [vp, PB, sz]),
     "mvk_set_params": (ip, [vp, PP]),
     "mvk_get_params": (ip, [vp, PP]),
+    "mvk_set_flag_precision": (ip, [vp, ip]),
+    "mvk_last_refined_count": (ip, [vp, C.POINTER(C.c_uint64)]),
     "mvk_set_profiling": (ip, [vp, ip]),
     "mvk_last_kernel_ms": (ip, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mvk_state_dim": (ip, [vp, ip]),

@@ -103,7 +103,11 @@ struct mvk_ctx {
   // of queue counters: call k appends to set k%2 and zeroes set (k+1)%2, so no memset sits between
   // launches.  Calls on one ctx must therefore be ordered with respect to each other (one stream at a time).
   static constexpr size_t kQueueCounterSet = static_cast<size_t>(MVK_MAX_SEG) * kQueueShards * kQueueCounterPitch;  // words
-  Buf queue, queue_rec, queue_counts;
+  Buf queue, queue_rec, queue_counts, refine_list;
+  int flag_precision = MVK_PRECISION_F64;  // mvk_set_flag_precision
+  float f32_delta_fk = 0.0f;
+  float f32_bound_scale = 1.0f;
+  const uint32_t* last_refine_counter = nullptr;  // device address of the last fp32-variant call's refine counter
   uint64_t call_index = 0;
   int n_cu = 256;
   // mvk_check_motion_batch_begin / _end
@@ -240,6 +244,46 @@ void derive_extras(const mvk_model* m, DevExtras* x) {
       }
     x->seg_sph[k][0] = c[0]; x->seg_sph[k][1] = c[1]; x->seg_sph[k][2] = c[2];
     x->seg_sph[k][3] = r * (1.0 + 1e-12) + 1e-12;
+  }
+  // fp32 copy of the model for the fp32 variant of the flag path, and the error constants of its frame walk:
+  // a rotation entry picks up <= 2.5e-7 per joint (fp32 sincos of an angle rounded to fp32) and <= 8 u per
+  // segment of rounding (u = 2^-24), plus the conversion of the root rotation; a frame origin that error
+  // times the lever (the robot's reach from the root)
+  {
+    ModelF32& f = x->f32;
+    double mass = 0.0;
+    for (int k = 0; k < m->n_seg; ++k) {
+      mass += m->seg_mass[k];
+      f.seg_mass[k] = static_cast<float>(m->seg_mass[k]);
+      for (int a = 0; a < 3; ++a) {
+        f.seg_t[k][a] = static_cast<float>(m->seg_t[k][a]);
+        f.seg_mcom[k][a] = static_cast<float>(m->seg_mass[k] * m->seg_com[k][a]);
+      }
+    }
+    for (int i = 0; i < m->n_rotor; ++i) {
+      for (int a = 0; a < 3; ++a) f.rotor_pos[i][a] = static_cast<float>(m->rotor_pos[i][a]);
+      f.rotor_ks[i] = static_cast<float>(m->m_f_rate * m->rotor_sigma[i]);
+    }
+    f.inv_mass = static_cast<float>(1.0 / mass);
+    f.weight = static_cast<float>(mass * m->gravity);
+    f.thrust_min = static_cast<float>(m->thrust_min);
+    f.thrust_max = static_cast<float>(m->thrust_max);
+    f.fc_t_thre = static_cast<float>(m->fc_t_min_thre);
+    f.fc_rp_thre = static_cast<float>(m->fc_rp_min_thre);
+    f.edf_offset_y = static_cast<float>(m->edf_offset_y);
+    f.edf_two_r = static_cast<float>(2.0 * m->edf_radius);
+    f.tan_edf_max_tilt = static_cast<float>(x->tan_edf_max_tilt);
+    const double u = 5.9604645e-8;
+    f.err_u = static_cast<float>(2.5e-7 * m->n_joint + 8.0 * u * (m->n_seg + 1));
+    f.err_p = static_cast<float>((2.5e-7 * m->n_joint + 8.0 * u * (m->n_seg + 1)) * x->reach);
+    for (int k = 0; k < m->n_seg; ++k) {
+      for (int a = 0; a < 4; ++a) x->seg_sph_f[k][a] = static_cast<float>(x->seg_sph[k][a]);
+      for (int j = 0; j < kSegPrimMax; ++j)
+        for (int a = 0; a < 3; ++a) {
+          x->seg_prim_pos_f[k][j][a] = static_cast<float>(x->seg_tab[k].prim_pos[j][a]);
+          x->seg_gimbal_pos_f[k][j][a] = static_cast<float>(x->seg_tab[k].gimbal_pos[j][a]);
+        }
+    }
   }
   for (int q = 0; q < m->n_prim; ++q) {
     const double* d = m->prim_dim[q];
@@ -382,6 +426,12 @@ int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
   // broadphase grid for the largest segment sphere (level-1 cull of the flag path)
   double rq = 0.0;
   for (int k = 0; k < c->model.n_seg; ++k) rq = std::fmax(rq, c->extras.seg_sph[k][3]);
+  // fp32 variant of the flag path: its frame walk places a segment centre within fk_err of the true one inside the
+  // fp32 coordinate range (<= 16 u of relative rounding per segment on coordinates up to `range`, plus the fp32
+  // cos/sin), so the cell it looks up must list every box within rq of any point that close: the grid is built
+  // for rq + 2 fk_err (a few tenths of a millimetre), and the fp32 thresholds are padded by f32_delta + fk_err
+  const double fk_err = 16.0 * 5.9604645e-8 * (c->model.n_seg + 1) * range + static_cast<double>(c->extras.f32.err_p);
+  rq += 2.0 * fk_err;
   GridHost gh;
   if (int rc = build_grid(host.data(), n, rq, gh)) return rc;
   if (int rc = c->obs.reserve(sizeof(DevObs) * (n ? n : 1))) return rc;
@@ -401,6 +451,7 @@ int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
   c->n_obs = static_cast<int>(n);
   c->f32_range = range;
   c->f32_delta = static_cast<float>(4e-6 * range);
+  c->f32_delta_fk = static_cast<float>(4e-6 * range + fk_err);
   return upload_distance_grids(c, host);
 }
 
@@ -438,6 +489,8 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
   a.dgrid_radius = c->dgrid_radius[0];
   a.f32_delta = c->f32_delta;
   a.f32_range = c->f32_range;
+  a.f32_delta_fk = c->f32_delta_fk;
+  a.f32_bound_scale = c->f32_bound_scale;
   a.n_obs = c->n_obs;
   a.nd_uniform = 1;
 }
@@ -474,6 +527,15 @@ int prepare_queue(mvk_ctx* c, EvalArgs& a, uint64_t n) {
   a.queue_rec = static_cast<double*>(c->queue_rec.p);
   // the exact stage runs as many blocks as the chip holds at once (about three per CU)
   a.exact_blocks = static_cast<uint32_t>(3 * c->n_cu);
+  if (c->flag_precision == MVK_PRECISION_F32_REFINED) {
+    if (int rc = c->refine_list.reserve(waves * 64 * sizeof(uint32_t))) return rc;
+    a.f32_walk = 1;
+    a.refine_list = static_cast<uint32_t*>(c->refine_list.p);
+    a.refine_count = a.queue_count + static_cast<size_t>(MVK_MAX_SEG * kQueueShards - 1) * kQueueCounterPitch;
+    c->last_refine_counter = a.refine_count;
+    const uint64_t blocks = (n + kBlock - 1) / kBlock;
+    a.refine_blocks = static_cast<uint32_t>(std::min<uint64_t>(blocks, static_cast<uint64_t>(2 * c->n_cu)));
+  }
   return MVK_OK;
 }
 
@@ -650,7 +712,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
   if (c->order_ev) (void)hipEventDestroy(c->order_ev);
   if (c->d_model) (void)hipFree(c->d_model);
   if (c->d_extras) (void)hipFree(c->d_extras);
-  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start[0], &c->dgrid_items[0], &c->dgrid_start[1], &c->dgrid_items[1], &c->queue, &c->queue_rec, &c->queue_counts, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
+  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start[0], &c->dgrid_items[0], &c->dgrid_start[1], &c->dgrid_items[1], &c->queue, &c->queue_rec, &c->queue_counts, &c->refine_list, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
                 &c->partial, &c->stats_out, &c->full_rec, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
   for (Buf* b : all) b->release();
@@ -679,6 +741,31 @@ extern "C" int mvk_set_params(mvk_ctx* c, const mvk_params* p) {
 extern "C" int mvk_get_params(const mvk_ctx* c, mvk_params* out) {
   if (!c || !out) return fail(MVK_ERR_INVALID_ARG, "null argument");
   *out = c->params;
+  return MVK_OK;
+}
+
+extern "C" int mvk_set_flag_precision(mvk_ctx* c, int precision) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  if (c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
+  if (precision != MVK_PRECISION_F64 && precision != MVK_PRECISION_F32_REFINED)
+    return fail(MVK_ERR_INVALID_ARG, "mvk_set_flag_precision: unknown precision %d", precision);
+  c->flag_precision = precision;
+  c->f32_bound_scale = 1.0f;
+  if (const char* e = std::getenv("MVK_F32_BOUND_SCALE")) {  // diagnostics: shrink the fp32 error bounds (tests of their safety margin)
+    const double v = std::atof(e);
+    if (v > 0.0 && v <= 64.0) c->f32_bound_scale = static_cast<float>(v);
+  }
+  return MVK_OK;
+}
+
+extern "C" int mvk_last_refined_count(mvk_ctx* c, uint64_t* out) {
+  if (!c || !out) return fail(MVK_ERR_INVALID_ARG, "null argument");
+  if (!c->last_refine_counter) return fail(MVK_ERR_INVALID_ARG, "mvk_last_refined_count: no call with MVK_PRECISION_F32_REFINED yet");
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->order_armed) HIP_TRY(hipEventSynchronize(c->order_ev));  // the last call on this ctx, whatever its stream
+  uint32_t v = 0;
+  HIP_TRY(hipMemcpy(&v, c->last_refine_counter, sizeof(v), hipMemcpyDeviceToHost));
+  *out = v;
   return MVK_OK;
 }
 
@@ -721,6 +808,34 @@ extern "C" int mvk_is_valid_mask_dev(mvk_ctx* c, const double* d_soa, size_t n, 
   if (!d_mask) return fail(MVK_ERR_INVALID_ARG, "null mask");
   return run_eval_dev(c, d_soa, n, ld, layout, nullptr, d_mask, nullptr, nullptr, nullptr, nullptr, false,
                       static_cast<hipStream_t>(stream));
+}
+
+// Diagnostic (not part of include/mvk.h; tests/test_gpu_f32.py, profiles/f32_bounds.py): one pass of the fp32 screen
+// stage over a batch that also writes, per state, what its stability classification worked with: d_lo = the
+// smallest (slack - error bound) over the tests it could bound, d_hi = the smallest (slack + error bound), d_cls =
+// 1 certainly stable / 0 certainly unstable / -1 uncertain (refined in fp64) / -2 non-finite input.
+extern "C" int mvk_debug_f32_bounds(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
+                                    double* d_lo, double* d_hi, double* d_cls, void* stream) {
+  if (!c || !d_soa || !d_lo || !d_hi || !d_cls || ld < n) return fail(MVK_ERR_INVALID_ARG, "mvk_debug_f32_bounds: bad argument");
+  if (n == 0) return MVK_OK;
+  const int rows = layout_rows(c, layout);
+  if (rows < 0) return rows;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int keep = c->flag_precision;
+  c->flag_precision = MVK_PRECISION_F32_REFINED;
+  EvalArgs a;
+  base_args(c, a);
+  a.soa = d_soa; a.n = n; a.ld = ld; a.layout = layout; a.flags = d_flags;
+  a.fc_t_min = d_lo; a.fc_rp_min = d_hi; a.rp_margin = d_cls;
+  c->stats_valid = false;
+  const int rc = prepare_queue(c, a, n);
+  c->flag_precision = keep;
+  if (rc) return rc;
+  if (int rc2 = enter_stream(c, s)) return rc2;
+  const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s, nullptr);
+  if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+  return leave_stream(c, s);
 }
 
 // The flag path with its hand-off buffers in the library's static __device__ scratch array: no hipMalloc, no

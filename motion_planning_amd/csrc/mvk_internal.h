@@ -46,6 +46,23 @@ struct SegTab {
   int32_t prim_frame[kSegPrimMax + 1];  // MVK_FRAME_*
 };
 
+// fp32 copy of the model constants for the fp32 variant of the flag path (walk 1 and the frames of walk 2 in
+// fp32): wave-uniform scalar loads of floats, no conversions in the kernel.  The err_* members are the bounds of
+// the fp32 evaluation errors the stability classification works with (derive_extras).
+struct ModelF32 {
+  float seg_t[MVK_MAX_SEG][3];
+  float seg_mcom[MVK_MAX_SEG][3];  // mass * centre of mass
+  float seg_mass[MVK_MAX_SEG];
+  float rotor_pos[MVK_MAX_ROTOR][3];
+  float rotor_ks[MVK_MAX_ROTOR];   // m_f_rate * sigma
+  float inv_mass, weight;          // 1 / total mass, total mass * gravity
+  float thrust_min, thrust_max, fc_t_thre, fc_rp_thre;
+  float edf_offset_y, edf_two_r, tan_edf_max_tilt;
+  float err_p;   // position of a frame origin relative to the root, incl. the joints' cos/sin errors [m]
+  float err_u;   // a component of a rotation matrix / thrust axis
+  float pad_[2];
+};
+
 struct DevExtras {
   double tan_edf_max_tilt;
   double prim_bound[MVK_MAX_PRIM];  // radius about the primitive origin containing it
@@ -56,6 +73,10 @@ struct DevExtras {
   double reach;                    // bound on the distance of any primitive point from the root origin
   double inv_mass;                 // 1 / total mass
   SegTab seg_tab[MVK_MAX_SEG];
+  ModelF32 f32;
+  float seg_sph_f[MVK_MAX_SEG][4];             // seg_sph in fp32
+  float seg_prim_pos_f[MVK_MAX_SEG][kSegPrimMax][3];    // SegTab::prim_pos in fp32
+  float seg_gimbal_pos_f[MVK_MAX_SEG][kSegPrimMax][3];  // SegTab::gimbal_pos in fp32
 };
 
 // ---- broadphase grid (mvk_grid.cpp) ---------------------------------------
@@ -111,6 +132,14 @@ struct EvalArgs {
   int32_t n_obs;
   float f32_delta;   // bound on the fp32 centre-distance error inside f32_range [m]
   double f32_range;  // coordinate magnitude up to which f32_delta holds
+  // fp32 variant of the flag path: f32_delta plus the bound of the fp32 frame walk's position error inside
+  // f32_range, and a scale on the stability error bounds (1; tests shrink it to show the safety margin)
+  float f32_delta_fk;
+  float f32_bound_scale;
+  int32_t f32_walk;        // 1: screen stage in fp32, uncertain states refined in fp64
+  uint32_t* refine_list;   // [n] state indices the fp32 screen hands to the fp64 screen
+  uint32_t* refine_count;  // one counter in the call's counter set
+  uint32_t refine_blocks;  // grid of the refine launch
   // outputs (nullable)
   uint8_t* flags;
   uint64_t* mask;

@@ -790,6 +790,364 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
 }
 
 // ------------------------------------------------------------------------
+// fp32 variant of the flag path: walk 1 in fp32 with error bounds
+// ------------------------------------------------------------------------
+// The stability verdict of a state is the sign of the smallest of a handful of slacks.  Here every slack s_t is
+// evaluated in fp32 together with a bound e_t of its fp32 evaluation error, built by first-order propagation from
+// two model constants (ModelF32::err_p / err_u: position and rotation-entry error of the fp32 frame walk, the
+// joints' fp32 cos/sin included) and doubled.  The verdict is taken in fp32 only when it cannot be wrong:
+//   every s_t - e_t > 0  -> certainly stable        some s_t + e_t < 0  -> certainly unstable
+// anything else (and every state whose normal matrix or gimbal is close to singular) is "uncertain" and is
+// evaluated again by the fp64 screen kernel, so the flags remain those of the fp64 semantics.
+DEV void sincos_f32(float x, float& s, float& c) {  // |x| up to a few hundred; ~1e-7 absolute
+  const float fn = rintf(x * 0.636619772f);
+  float r = fmaf(-fn, 1.57079637f, x);
+  r = fmaf(-fn, -4.37113883e-8f, r);
+  const int q = static_cast<int>(fn);
+  const float z = r * r;
+  float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(z, ps, -1.6666654611e-1f);
+  const float sr = fmaf(r * z, ps, r);
+  float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(z, pc, 4.166664568298827e-2f);
+  const float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+  const float a = (q & 1) ? cr : sr;
+  const float b = (q & 1) ? sr : cr;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+
+DEV float rsqrt_f32(float x) {  // hardware estimate + one Newton step
+  const float y = __builtin_amdgcn_rsqf(x);
+  return fmaf(y, fmaf(-0.5f * x * y, y, 0.5f), y);
+}
+
+template <int AXIS>
+DEV void rot_cols_f(float R[9], float c, float s) {
+  constexpr int a = (AXIS + 1) % 3, b = (AXIS + 2) % 3;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float ua = R[3 * r + a], ub = R[3 * r + b];
+    R[3 * r + a] = fmaf(c, ua, s * ub);
+    R[3 * r + b] = fmaf(c, ub, -s * ua);
+  }
+}
+DEV void rot_cols_dyn_f(float R[9], int axis, float c, float s) {
+  if (axis == 0) rot_cols_f<0>(R, c, s);
+  else if (axis == 1) rot_cols_f<1>(R, c, s);
+  else rot_cols_f<2>(R, c, s);
+}
+DEV void xform_f(const float R[9], const float p[3], float tx, float ty, float tz, float y[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) y[r] = fmaf(R[3 * r], tx, fmaf(R[3 * r + 1], ty, fmaf(R[3 * r + 2], tz, p[r])));
+}
+
+constexpr float kF32U = 5.9604645e-8f;  // 2^-24
+
+// returns 1: certainly stable, 0: certainly unstable, -1: uncertain.  Leaves the joints' fp32 cos/sin in
+// csf[(2j) * kBlock + tid], csf[(2j+1) * kBlock + tid] for walk 2.  Rf = float(Rw).
+// dbg (nullable): [0] smallest s - e, [1] smallest s + e over the tests that could be bounded, [2] 1 when a test could not
+template <int ROBOT, int NL>
+DEV int model_update_f32(const EvalArgs& A, const DevExtras* __restrict__ X, const double* st, const float Rf[9],
+                         lds_float* csf, float* dbg) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NS = S::kSeg, NJ = S::kJoint, D = S::kDof;
+  const ModelF32& F = X->f32;
+  const int tid = threadIdx.x;
+  float jc[NJ], js[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    sincos_f32(static_cast<float>(st[7 + j]), js[j], jc[j]);
+    csf[(2 * j) * kBlock + tid] = jc[j];
+    csf[(2 * j + 1) * kBlock + tid] = js[j];
+  }
+  const float bs = 2.0f * A.f32_bound_scale;
+  // frame walk relative to the root origin (stability does not depend on the root position)
+  float R[9], p[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = Rf[k];
+  float cog[3] = {0.0f, 0.0f, 0.0f};
+  float P[NL][3], U[NL][3];
+  float E[S::kGimbal ? 2 * NL : 1][3];
+  float err_u = F.err_u;  // (gimbal models: grows with the conditioning of the gimbal solve)
+  bool unc = false;
+  static_for<0, NS>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k > 0) {
+      float pn[3];
+      xform_f(R, p, F.seg_t[k][0], F.seg_t[k][1], F.seg_t[k][2], pn);
+      p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+      rot_cols_f<S::axis(k)>(R, jc[S::joint(k)], js[S::joint(k)]);
+    }
+    float cw[3];
+    const float z3[3] = {0.0f, 0.0f, 0.0f};
+    xform_f(R, z3, F.seg_mcom[k][0], F.seg_mcom[k][1], F.seg_mcom[k][2], cw);  // mass * R * com
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cog[c] += fmaf(F.seg_mass[k], p[c], cw[c]);
+    const bool is_rotor_seg = S::kGimbal ? ((k & 1) == 0) : true;
+    if (is_rotor_seg) {
+      const int i = S::kGimbal ? k / 2 : k;
+      xform_f(R, p, F.rotor_pos[i][0], F.rotor_pos[i][1], F.rotor_pos[i][2], P[i]);
+      if (S::kGimbal) {
+        const float zlx = R[6], zly = R[7], zlz = R[8];
+        const float rho2 = fmaf(zly, zly, zlz * zlz);
+        unc = unc || !(rho2 > 1e-2f);  // gimbal solve ill conditioned: the fp64 kernel decides
+        const float ir = rsqrt_f32(rho2);
+        const float cr = zlz * ir, sr = -zly * ir;
+        const float w = fmaf(-zly, sr, zlz * cr);
+        const float nn = rsqrt_f32(fmaf(zlx, zlx, w * w));
+        const float cp = w * nn, sp = zlx * nn;
+        err_u = fmaxf(err_u, 6.0f * F.err_u * ir);
+        const float ux = sp, uy = -sr * cp, uz = cr * cp;
+        const float ey = cr, ez = sr;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          U[i][r] = fmaf(R[3 * r], ux, fmaf(R[3 * r + 1], uy, R[3 * r + 2] * uz));
+          const float yw = fmaf(R[3 * r + 1], ey, R[3 * r + 2] * ez) * F.edf_offset_y;
+          E[2 * i][r] = P[i][r] + yw;
+          E[2 * i + 1][r] = P[i][r] - yw;
+        }
+      } else {
+        U[i][0] = R[2]; U[i][1] = R[5]; U[i][2] = R[8];
+      }
+    }
+  });
+#pragma unroll
+  for (int c = 0; c < 3; ++c) cog[c] *= F.inv_mass;
+  float Pm = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      P[i][c] -= cog[c];
+      Pm = fmaxf(Pm, fabsf(P[i][c]));
+    }
+  // V = P x U + ks U and a bound on the error of every component: P (relative to the CoG) carries 2 err_p per
+  // component, U carries err_ua (planar chains: every thrust axis IS the root's z axis, only its conversion to
+  // fp32 counts; gimbal models: err_u grown by the conditioning of the gimbal solve), plus the rounding of the
+  // three products.  Component-wise, because the rows of the wrench matrix differ in scale by orders of
+  // magnitude (planar HYDRUS: the yaw-torque row is +-kappa).
+  const float err_ua = bs * (S::kGimbal ? err_u : 2.0f * kF32U);
+  const float err_pc = bs * 2.0f * F.err_p;
+  float V[NL][3], dVc[NL][3], Vm = 1.0f, dV = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const float ks = F.rotor_ks[i];
+    V[i][0] = fmaf(P[i][1], U[i][2], fmaf(-P[i][2], U[i][1], ks * U[i][0]));
+    V[i][1] = fmaf(P[i][2], U[i][0], fmaf(-P[i][0], U[i][2], ks * U[i][1]));
+    V[i][2] = fmaf(P[i][0], U[i][1], fmaf(-P[i][1], U[i][0], ks * U[i][2]));
+    const float au[3] = {fabsf(U[i][0]), fabsf(U[i][1]), fabsf(U[i][2])};
+    const float ap[3] = {fabsf(P[i][0]), fabsf(P[i][1]), fabsf(P[i][2])};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+      const float mag = fmaf(ap[c1], au[c2], fmaf(ap[c2], au[c1], fabsf(ks) * au[c]));
+      dVc[i][c] = fmaf(err_pc, au[c1] + au[c2], fmaf(err_ua, ap[c1] + ap[c2] + fabsf(ks), 4.0f * kF32U * mag));
+      dV = fmaxf(dV, dVc[i][c]);
+    }
+    Vm = fmaxf(Vm, fmaxf(fabsf(V[i][0]), fmaxf(fabsf(V[i][1]), fabsf(V[i][2]))));
+  }
+  float lo = INFINITY, hi = INFINITY;  // smallest s - e, smallest s + e
+  auto test = [&](float sl, float e) { lo = fminf(lo, sl - e); hi = fminf(hi, sl + e); };
+
+  // ---- static thrust: lambda = A^T (A A^T)^-1 b on rows {fz, tx, ty, (tz)} ----------------
+  // First-order perturbation of the minimum-norm solution for A -> A + E, |E_ri| <= dA_ri:
+  //   d lambda = -A^+ E lambda + (I - A^+ A) E^T y,  y = G^-1 b,  A^+ = A^T G^-1,  G = A A^T
+  //   |d lambda_i| <= sum_r |a_ri| (|G^-1| |E| |lambda|)_r + sum_r dA_ri |y_r|
+  // with |G^-1| taken entry-wise from the inverse of the Cholesky factor; the rounding of the fp32 solve itself is
+  // a relative perturbation of A of a few u (folded into dA).
+  {
+    float G[D][D];
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const float ar = r == 0 ? U[i][2] : V[i][r - 1];
+          const float ac = c == 0 ? U[i][2] : V[i][c - 1];
+          acc = fmaf(ar, ac, acc);
+        }
+        G[r][c] = acc;
+      }
+    float Lm[D][D], Linv[D];
+    bool weak = false;
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        float acc = G[r][c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) acc = fmaf(-Lm[r][k], Lm[c][k], acc);
+        if (r == c) {
+          weak = weak || !(acc > 1e-3f * G[r][r]);  // the row is (almost) a combination of the rows before it
+          Linv[r] = rsqrt_f32(acc);
+          Lm[r][r] = acc * Linv[r];
+        } else {
+          Lm[r][c] = acc * Linv[c];
+        }
+      }
+    float Li[D][D];  // inverse of the Cholesky factor (lower triangular)
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+#pragma unroll
+      for (int r = c; r < D; ++r) {
+        float acc = r == c ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = c; k < r; ++k) acc = fmaf(-Lm[r][k], Li[k][c], acc);
+        Li[r][c] = acc * Linv[r];
+      }
+    // y = G^-1 b with b = weight * e0, and |G^-1| <= |Li|^T |Li| entry-wise
+    float yb[D], Gi[D][D];
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = r; k < D; ++k) acc = fmaf(Li[k][r], Li[k][0], acc);
+      yb[r] = acc * F.weight;
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        float g = 0.0f;
+#pragma unroll
+        for (int k = r; k < D; ++k) g = fmaf(fabsf(Li[k][r]), fabsf(Li[k][c]), g);
+        Gi[r][c] = g;
+        Gi[c][r] = g;
+      }
+    }
+    float lam[NL], lam_min = INFINITY, lam_max = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float acc = U[i][2] * yb[0];
+#pragma unroll
+      for (int r = 1; r < D; ++r) acc = fmaf(V[i][r - 1], yb[r], acc);
+      lam[i] = acc;
+      lam_min = fminf(lam_min, acc);
+      lam_max = fmaxf(lam_max, acc);
+    }
+    float El[D];  // (|E| |lambda|)_r
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const float a_ri = r == 0 ? U[i][2] : V[i][r - 1];
+        const float d_ri = (r == 0 ? err_ua : dVc[i][r - 1]) + 16.0f * kF32U * fabsf(a_ri);
+        acc = fmaf(d_ri, fabsf(lam[i]), acc);
+      }
+      El[r] = acc;
+    }
+    float w[D];
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc = fmaf(Gi[r][c], El[c], acc);
+      w[r] = acc;
+    }
+    float e_lam = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        const float a_ri = r == 0 ? U[i][2] : V[i][r - 1];
+        const float d_ri = (r == 0 ? err_ua : dVc[i][r - 1]) + 16.0f * kF32U * fabsf(a_ri);
+        acc = fmaf(fabsf(a_ri), w[r], fmaf(d_ri, fabsf(yb[r]), acc));
+      }
+      e_lam = fmaxf(e_lam, acc);
+    }
+    e_lam = fmaf(8.0f * kF32U, fmaxf(fabsf(lam_min), fabsf(lam_max)), e_lam);
+    if (weak || !(e_lam < INFINITY)) unc = true;
+    else {
+      test(lam_min - F.thrust_min, e_lam);
+      test(F.thrust_max - lam_max, e_lam);
+    }
+  }
+
+  float Vs[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { Vs[0] += V[i][0]; Vs[1] += V[i][1]; Vs[2] += V[i][2]; }
+  const float half_fmax = 0.5f * F.thrust_max;
+  const float e_c = 4.0f * Vm * dV + 8.0f * kF32U * Vm * Vm;  // a component of V_i x V_j (norm-wise)
+  // ---- feasible-control torque distances (as model_update: distance * |n| against threshold * |n|) ----
+  // Error bounds component by component: the triple products n . V_k are small differences of large terms
+  // whenever the thrust axes are (nearly) parallel -- every planar chain -- and a norm-wise bound would swamp them.
+  if (F.fc_t_thre > 0.0f) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+      for (int j = i + 1; j < NL; ++j) {
+        float nv[3], dn[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+          nv[c] = fmaf(V[i][c1], V[j][c2], -V[i][c2] * V[j][c1]);
+          const float mag = fmaf(fabsf(V[i][c1]), fabsf(V[j][c2]), fabsf(V[i][c2] * V[j][c1]));
+          dn[c] = fmaf(fabsf(V[i][c1]), dVc[j][c2], fmaf(fabsf(V[j][c2]), dVc[i][c1],
+                  fmaf(fabsf(V[i][c2]), dVc[j][c1], fmaf(fabsf(V[j][c1]), dVc[i][c2], 4.0f * kF32U * mag))));
+        }
+        const float n2 = fmaf(nv[0], nv[0], fmaf(nv[1], nv[1], nv[2] * nv[2]));
+        const float an[3] = {fabsf(nv[0]), fabsf(nv[1]), fabsf(nv[2])};
+        float sabs = 0.0f, e_sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+          // (k = i, j: exactly 0 in exact arithmetic; they enter ssum below with their rounding, bounded the same way)
+          const float t = fmaf(nv[0], V[k][0], fmaf(nv[1], V[k][1], nv[2] * V[k][2]));
+          const float mag = fmaf(an[0], fabsf(V[k][0]), fmaf(an[1], fabsf(V[k][1]), an[2] * fabsf(V[k][2])));
+          e_sum += fmaf(an[0], dVc[k][0], fmaf(an[1], dVc[k][1], fmaf(an[2], dVc[k][2],
+                   fmaf(fabsf(V[k][0]), dn[0], fmaf(fabsf(V[k][1]), dn[1], fmaf(fabsf(V[k][2]), dn[2], 4.0f * kF32U * mag))))));
+          if (k != i && k != j) sabs += fabsf(t);
+        }
+        const float ssum = fmaf(nv[0], Vs[0], fmaf(nv[1], Vs[1], nv[2] * Vs[2]));
+        const float dist_n = fmaxf(sabs - fabsf(ssum), 0.0f) * half_fmax;
+        const float nn = sqrtf(n2);
+        const float e_nn = dn[0] + dn[1] + dn[2];
+        const float e = fmaf(half_fmax, 2.0f * e_sum + 8.0f * kF32U * (sabs + fabsf(ssum)), F.fc_t_thre * e_nn);
+        // the fp64 rule "|n| < 1e-5 -> distance 0" must be decidable as well
+        if (!(nn > 1e-5f + 2.0f * e_nn)) unc = true;
+        else test(dist_n - F.fc_t_thre * nn, e);
+      }
+  }
+  // ---- roll / pitch distances ----
+  if (F.fc_rp_thre > 0.0f) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float na2 = fmaf(V[i][0], V[i][0], V[i][1] * V[i][1]);
+      float sabs = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        if (j == i) continue;
+        sabs += fabsf(fmaf(V[i][1], V[j][0], -V[i][0] * V[j][1]));
+      }
+      const float ssum = fmaf(V[i][1], Vs[0], -V[i][0] * Vs[1]);
+      const float dist_n = fmaxf(sabs + ssum, 0.0f) * half_fmax;
+      const float na = sqrtf(na2);
+      const float e = half_fmax * (2.0f * NL) * e_c + F.fc_rp_thre * 2.0f * dV;
+      if (!(na > 1e-5f + 4.0f * dV)) unc = true;
+      else test(dist_n - F.fc_rp_thre * na, e);
+    }
+  }
+  // ---- EDF overlap (gimbal models) ----
+  if (S::kGimbal) {
+    const float dE = bs * (4.0f * F.err_p + 4.0f * F.edf_offset_y * err_u + 8.0f * kF32U * (Pm + 1.0f));
+#pragma unroll
+    for (int a = 0; a < 2 * NL; ++a)
+#pragma unroll
+      for (int b = a + 1; b < 2 * NL; ++b) {
+        if (a / 2 == b / 2) continue;
+        const float dx = E[a][0] - E[b][0], dy = E[a][1] - E[b][1], dz = E[a][2] - E[b][2];
+        const float h = sqrtf(fmaf(dx, dx, dy * dy)), c = fmaf(fabsf(dz), F.tan_edf_max_tilt, F.edf_two_r);
+        test(h - c, (2.0f + F.tan_edf_max_tilt) * dE);
+      }
+  }
+  if (dbg) { dbg[0] = lo; dbg[1] = hi; dbg[2] = unc ? 1.0f : 0.0f; }
+  if (hi < 0.0f) return 0;            // some test certainly fails (NaN compares false: uncertain)
+  if (!unc && lo > 0.0f) return 1;    // every test certainly passes
+  return -1;
+}
+
+// ------------------------------------------------------------------------
 // walk 2 building blocks: the chain frame, primitive poses, box-frame tests
 // ------------------------------------------------------------------------
 // frame of segment k from the frame of segment k-1; joint cos/sin from LDS slot `src`
@@ -988,14 +1346,14 @@ struct ScreenLds {
 };
 
 // screen thresholds of the primitive in slot j of segment k (see PrimF32 above)
-DEV void screen_thresholds(const EvalArgs& A, const DevExtras* __restrict__ X, int k, int j, float& hit2, float& may2) {
+DEV void screen_thresholds(const EvalArgs& A, const DevExtras* __restrict__ X, int k, int j, float delta, float& hit2, float& may2) {
   const int pb = X->seg_prim_begin[k], np = X->seg_prim_begin[k + 1] - pb;
   hit2 = -1.0f;
   may2 = -1.0f;
   if (j < np) {
     const int q = X->prim_order[pb + j];
-    const float rin = static_cast<float>(X->prim_inner[q]) * 0.999999f - A.f32_delta;
-    const float rb = (static_cast<float>(X->prim_bound[q]) + A.f32_delta) * 1.000001f;
+    const float rin = static_cast<float>(X->prim_inner[q]) * 0.999999f - delta;
+    const float rb = (static_cast<float>(X->prim_bound[q]) + delta) * 1.000001f;
     hit2 = rin > 0.0f ? rin * rin : -1.0f;
     may2 = rb * rb;
   }
@@ -1162,6 +1520,125 @@ DEV void collide_screen(const EvalArgs& A, const mvk_model* __restrict__ M, cons
 #ifdef MVK_PROFS
   *prof_pop += wall_clock64() - tp1;
 #endif
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const unsigned r = __hip_atomic_load(L.res + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  hit = live && (r & kResHit);
+  segmask = live ? (r & ~kResHit) : 0u;
+}
+
+// level 0 for the fp32 frame walk: the grid's radius is padded by the walk's position error bound (mvk_capi.cpp,
+// upload_scene), so a centre that is off by that much still finds every box within the segment radius in its cell
+DEV void grid_cell_f(const GridDev& G, const float c[3], bool on, unsigned& gb, unsigned& ge) {
+  const float ih = static_cast<float>(G.inv_h);
+  const float gx = (c[0] - static_cast<float>(G.origin[0])) * ih, gy = (c[1] - static_cast<float>(G.origin[1])) * ih,
+              gz = (c[2] - static_cast<float>(G.origin[2])) * ih;
+  const bool inside = on && gx >= 0.0f && gy >= 0.0f && gz >= 0.0f && gx < static_cast<float>(G.n[0]) &&
+                      gy < static_cast<float>(G.n[1]) && gz < static_cast<float>(G.n[2]);
+  gb = 0; ge = 0;
+  if (inside) {
+    const unsigned cell = (static_cast<unsigned>(static_cast<int>(gz)) * G.n[1] + static_cast<unsigned>(static_cast<int>(gy))) * G.n[0] +
+                          static_cast<unsigned>(static_cast<int>(gx));
+    gb = G.start[cell];
+    ge = G.start[cell + 1];
+  }
+}
+
+// collide_screen with the chain frames in fp32 (fp32 variant of the flag path): same ring, same pops; the
+// thresholds in L.thr carry f32_delta_fk, which covers the frame walk's position error as well.  Only lanes
+// inside the fp32 coordinate range come here (the others are refined in fp64).
+template <int ROBOT, int NL>
+DEV void collide_screen_f32(const EvalArgs& A, const DevExtras* __restrict__ X, const DevObsF* __restrict__ obsf,
+                            const double pos[3], const float Rf[9], const lds_float* csf, const ScreenLds& L, bool live,
+                            bool& hit, unsigned& segmask) {
+  using S = Shape<ROBOT, NL>;
+  const ModelF32& F = X->f32;
+  const int tid = threadIdx.x, lane = threadIdx.x & 63;
+  float R[9], p[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = Rf[k];
+  p[0] = static_cast<float>(pos[0]); p[1] = static_cast<float>(pos[1]); p[2] = static_cast<float>(pos[2]);
+  L.res[lane] = 0u;
+  unsigned head = 0, qn = 0;  // wave-uniform
+  auto push_item = [&](const float* c, unsigned gb, unsigned ge, unsigned tag_a, unsigned tag_b) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const bool push = gb < ge && !(__hip_atomic_load(L.res + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) & kResHit);
+    const unsigned long long bal = __ballot(push);
+    if (bal) {
+      const unsigned to = (head + qn + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)))) & (kRing - 1);
+      if (push) {
+#pragma unroll
+        for (int e = 0; e < 3 * kSegPrimMax; ++e) L.ring[e * kRing + to] = __float_as_uint(c[e]);
+        L.ring[(3 * kSegPrimMax) * kRing + to] = gb | tag_a;
+        L.ring[(3 * kSegPrimMax + 1) * kRing + to] = ge | tag_b;
+      }
+      qn += static_cast<unsigned>(__popcll(bal));
+    }
+  };
+  float pc_[3 * kSegPrimMax];
+  unsigned p_gb = 0, p_ge = 0, p_ta = 0, p_tb = 0;
+  bool pending = false;  // wave-uniform
+#pragma unroll 1
+  for (int k = 0; k < S::kSeg; ++k) {
+    const SegTab& T = X->seg_tab[k];
+    if (k > 0) {
+      float pn[3];
+      xform_f(R, p, F.seg_t[k][0], F.seg_t[k][1], F.seg_t[k][2], pn);
+      p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+      rot_cols_dyn_f(R, T.axis, csf[(2 * T.joint) * kBlock + tid], csf[(2 * T.joint + 1) * kBlock + tid]);
+    }
+    const int np = T.np;
+    if (np == 0) continue;
+    float sc[3];
+    xform_f(R, p, X->seg_sph_f[k][0], X->seg_sph_f[k][1], X->seg_sph_f[k][2], sc);
+    unsigned gb, ge;
+    grid_cell_f(A.grid, sc, live, gb, ge);
+    float gcr = 1.0f, gsr = 0.0f, gcp = 1.0f, gsp = 0.0f;
+    if (S::kGimbal && T.pad) {
+      const float zlx = R[6], zly = R[7], zlz = R[8];
+      const float rho2 = fmaf(zly, zly, zlz * zlz);
+      const bool deg = !(rho2 > 0.0f);
+      const float ir = rsqrt_f32(rho2);
+      gcr = deg ? 1.0f : zlz * ir;
+      gsr = deg ? 0.0f : -zly * ir;
+      const float w = fmaf(-zly, gsr, zlz * gcr);
+      const float nn = rsqrt_f32(fmaf(zlx, zlx, w * w));
+      gcp = w * nn;
+      gsp = zlx * nn;
+    }
+    float c[3 * kSegPrimMax];
+#pragma unroll
+    for (int j = 0; j < kSegPrimMax; ++j) {
+      c[3 * j] = c[3 * j + 1] = c[3 * j + 2] = 0.0f;
+      if (j < np) {
+        float pc[3];
+        if (S::kGimbal && T.prim_frame[j] != MVK_FRAME_SEG) {
+          float B[9], o[3];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) B[e] = R[e];
+          xform_f(R, p, X->seg_gimbal_pos_f[k][j][0], X->seg_gimbal_pos_f[k][j][1], X->seg_gimbal_pos_f[k][j][2], o);
+          rot_cols_f<0>(B, gcr, gsr);
+          if (T.prim_frame[j] == MVK_FRAME_GIMBAL_PITCH) rot_cols_f<1>(B, gcp, gsp);
+          xform_f(B, o, X->seg_prim_pos_f[k][j][0], X->seg_prim_pos_f[k][j][1], X->seg_prim_pos_f[k][j][2], pc);
+        } else {
+          xform_f(R, p, X->seg_prim_pos_f[k][j][0], X->seg_prim_pos_f[k][j][1], X->seg_prim_pos_f[k][j][2], pc);
+        }
+        c[3 * j] = pc[0]; c[3 * j + 1] = pc[1]; c[3 * j + 2] = pc[2];
+      }
+    }
+    if (pending) push_item(pc_, p_gb, p_ge, p_ta, p_tb);
+#pragma unroll
+    for (int e = 0; e < 3 * kSegPrimMax; ++e) pc_[e] = c[e];
+    p_gb = gb; p_ge = ge;
+    p_ta = (static_cast<unsigned>(lane) << 21) | (static_cast<unsigned>(k) << 27) | (1u << 31);
+    p_tb = static_cast<unsigned>(np) << 22;
+    pending = true;
+#pragma unroll 1
+    while (qn >= 64u) screen_pop(A, obsf, L, head, qn);
+  }
+  if (pending) push_item(pc_, p_gb, p_ge, p_ta, p_tb);
+#pragma unroll 1
+  while (qn > 0u) screen_pop(A, obsf, L, head, qn);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const unsigned r = __hip_atomic_load(L.res + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1884,34 +2361,59 @@ DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t
 //                   instead of the whole chain).  Exact fp64 tests; a collision clears the state's flag / mask
 //                   bit (or lowers first_invalid of its edge).
 // Full path = full_kernel: exact minimum distance, margins, details and statistics, no early exit.
-template <int ROBOT, int NL, bool EDGE>
-__global__ void __launch_bounds__(kBlock, (Shape<ROBOT, NL>::kScreenWaves))
-screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
-              const DevObsF* __restrict__ obsf) {
+constexpr int kRefineSlot = MVK_MAX_SEG * kQueueShards - 1;  // counter of the refine list, in each counter set
+
+// Hand the undecided (state, segment) pairs of a wave to the exact stage.  Wave by wave and without a block barrier:
+// lane k of the wave reserves the wave's share of segment k's queue with one atomic (the queues are split
+// kQueueShards ways by wave index, so that no counter sees more than a few thousand atomics per launch), the lanes
+// write their state index behind it.  SCATTERED (the lanes' states come from a list, not from one wave of the batch):
+// one atomic per lane and segment on the shard of the lane's own state, whose quota nobody else uses.
+template <int ROBOT, int NL, bool SCATTERED>
+DEV void enqueue_undecided(const EvalArgs& A, uint64_t gi, unsigned todo) {
+  using S = Shape<ROBOT, NL>;
+  const int lane = threadIdx.x & 63;
+  const unsigned shard = static_cast<unsigned>(gi >> 6) & (kQueueShards - 1);
+  if (SCATTERED) {
+#pragma unroll
+    for (int k = 0; k < S::kSeg; ++k)
+      if ((todo >> k) & 1u) {
+        const unsigned at = atomicAdd(A.queue_count + (k * kQueueShards + shard) * kQueueCounterPitch, 1u);
+        A.queue[static_cast<uint64_t>(k * kQueueShards + shard) * A.queue_stride + at] = static_cast<uint32_t>(gi);
+      }
+    return;
+  }
+  unsigned long long bal[S::kSeg];
+  unsigned my_cnt = 0;
+#pragma unroll
+  for (int k = 0; k < S::kSeg; ++k) {
+    bal[k] = __ballot((todo >> k) & 1u);
+    my_cnt = (lane == k) ? static_cast<unsigned>(__popcll(bal[k])) : my_cnt;
+  }
+  unsigned my_base = 0;
+  if (lane < S::kSeg && my_cnt) my_base = atomicAdd(A.queue_count + (lane * kQueueShards + shard) * kQueueCounterPitch, my_cnt);
+#pragma unroll
+  for (int k = 0; k < S::kSeg; ++k) {
+    const unsigned base_k = __builtin_amdgcn_readlane(my_base, k);
+    if ((todo >> k) & 1u)
+      A.queue[static_cast<uint64_t>(k * kQueueShards + shard) * A.queue_stride + base_k + __popcll(bal[k] & ((1ull << lane) - 1ull))] =
+          static_cast<uint32_t>(gi);
+  }
+}
+
+// REFINE: the states come from the list the fp32 screen left (fp32 variant of the flag path): a fixed grid strides
+// over it; a state was written "valid so far", so only a negative verdict is written (as the exact stage does).
+// one state per lane through the fp64 screen stage: gi = the state's index in the batch (li = the index it reads:
+// out-of-range lanes redo the last state), in_range = the lane owns a state
+template <int ROBOT, int NL, bool EDGE, bool REFINE>
+DEV void screen_body(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                     const DevObsF* __restrict__ obsf, const Smem& sm, const ScreenLds& L, uint64_t gi, uint64_t li,
+                     bool in_range, unsigned long long t_entry) {
   using S = Shape<ROBOT, NL>;
   constexpr int NJ = S::kJoint;
-  __shared__ double sm_cs[2 * NJ * kBlock];
-  __shared__ unsigned sm_ring[(kBlock / 64) * kRingWords * kRing];
-  __shared__ unsigned sm_res[kBlock];
-  __shared__ float sm_thr[S::kSeg * kSegPrimMax * 2];
-  Smem sm{(lds_double*)sm_cs, nullptr};
-#ifdef MVK_PROFS
-  const unsigned long long t_entry = wall_clock64();
-#endif
-  const ScreenLds L{(lds_uint*)sm_ring + (threadIdx.x >> 6) * (kRingWords * kRing), (lds_uint*)sm_res + (threadIdx.x & ~63), (lds_float*)sm_thr};
-  if (threadIdx.x < S::kSeg * kSegPrimMax) {
-    float h2, m2;
-    screen_thresholds(A, X, threadIdx.x / kSegPrimMax, threadIdx.x % kSegPrimMax, h2, m2);
-    L.thr[2 * threadIdx.x] = h2;
-    L.thr[2 * threadIdx.x + 1] = m2;
-  }
-  __syncthreads();
-
-  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  const bool in_range = gi < A.n;
-  const uint64_t li = in_range ? gi : (A.n - 1);  // clamp: out-of-range lanes redo the last state
+  (void)t_entry;
   // the counters the NEXT call on this ctx appends to
-  if (gi < static_cast<uint64_t>(S::kSeg * kQueueShards)) A.queue_count_next[gi * kQueueCounterPitch] = 0u;
+  if (!REFINE && (gi < static_cast<uint64_t>(S::kSeg * kQueueShards) || gi == static_cast<uint64_t>(kRefineSlot)))
+    A.queue_count_next[gi * kQueueCounterPitch] = 0u;
 
   double st[7 + NJ];
   uint64_t edge;
@@ -1942,32 +2444,12 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
   const bool undecided = in_range && live && !hit && segmask != 0u;
   PROF_LANES(0, true); PROF_LANES(1, live); PROF_LANES(2, hit); PROF_LANES(3, undecided); PROF_LANES(4, live && !hit && segmask == 0u);
 
-  // Hand the undecided (state, segment) pairs to the exact stage, wave by wave and without a block
-  // barrier: lane k of the wave reserves the wave's share of segment k's queue with one atomic (the
-  // queues are split kQueueShards ways by wave index, so that no counter sees more than a few
-  // thousand atomics per launch), the lanes write their state index behind it, and an undecided
-  // lane leaves its record (root pose, joint cos/sin) in the slot of its state.
+  // hand-off to the exact stage: queue entries, and an undecided lane leaves its record (root pose, joint
+  // cos/sin) in the slot of its state
   {
     const unsigned todo = undecided ? segmask : 0u;
     if (__any(todo != 0u)) {
-      const int lane = threadIdx.x & 63;
-      const unsigned shard = static_cast<unsigned>(gi >> 6) & (kQueueShards - 1);
-      unsigned long long bal[S::kSeg];
-      unsigned my_cnt = 0;
-#pragma unroll
-      for (int k = 0; k < S::kSeg; ++k) {
-        bal[k] = __ballot((todo >> k) & 1u);
-        my_cnt = (lane == k) ? static_cast<unsigned>(__popcll(bal[k])) : my_cnt;
-      }
-      unsigned my_base = 0;
-      if (lane < S::kSeg && my_cnt) my_base = atomicAdd(A.queue_count + (lane * kQueueShards + shard) * kQueueCounterPitch, my_cnt);
-#pragma unroll
-      for (int k = 0; k < S::kSeg; ++k) {
-        const unsigned base_k = __builtin_amdgcn_readlane(my_base, k);
-        if ((todo >> k) & 1u)
-          A.queue[static_cast<uint64_t>(k * kQueueShards + shard) * A.queue_stride + base_k + __popcll(bal[k] & ((1ull << lane) - 1ull))] =
-              static_cast<uint32_t>(gi);
-      }
+      enqueue_undecided<ROBOT, NL, REFINE>(A, gi, todo);
       if (todo != 0u) {
         double2* __restrict__ dst = reinterpret_cast<double2*>(A.queue_rec + gi * S::kRecPad);
         dst[0] = make_double2(st[0], st[1]);
@@ -1982,7 +2464,16 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
 
   const bool valid = finite && (!A.do_stab || o.stable) && !hit;
   const bool band = !finite || (A.do_stab && fabs(o.margin) <= A.eps_margin);
-  if (!EDGE) {
+  if (REFINE) {
+    if (in_range && !valid) {  // the fp32 screen wrote this state as valid-so-far
+      if (!EDGE) {
+        if (A.flags) A.flags[gi] = 0;
+        if (A.mask) atomicAnd(reinterpret_cast<unsigned long long*>(A.mask) + (gi >> 6), ~(1ull << (gi & 63)));
+      } else {
+        atomicMin(&A.first_invalid[edge], step);
+      }
+    }
+  } else if (!EDGE) {
     if (in_range) {
       if (A.flags) A.flags[gi] = valid ? 1 : 0;
       if (A.band) A.band[gi] = band ? 1 : 0;
@@ -1999,6 +2490,166 @@ screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras
   { const unsigned long long t_end = wall_clock64(); prof_d[3] += t_end - t_w2; }
   PROF_STAGE_FLUSH;
 #endif
+}
+
+template <int ROBOT, int NL, bool EDGE, bool REFINE>
+__global__ void __launch_bounds__(kBlock, (Shape<ROBOT, NL>::kScreenWaves))
+screen_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+              const DevObsF* __restrict__ obsf) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ double sm_cs[2 * NJ * kBlock];
+  __shared__ unsigned sm_ring[(kBlock / 64) * kRingWords * kRing];
+  __shared__ unsigned sm_res[kBlock];
+  __shared__ float sm_thr[S::kSeg * kSegPrimMax * 2];
+  Smem sm{(lds_double*)sm_cs, nullptr};
+#ifdef MVK_PROFS
+  const unsigned long long t_entry = wall_clock64();
+#else
+  const unsigned long long t_entry = 0;
+#endif
+  const ScreenLds L{(lds_uint*)sm_ring + (threadIdx.x >> 6) * (kRingWords * kRing), (lds_uint*)sm_res + (threadIdx.x & ~63), (lds_float*)sm_thr};
+  if (threadIdx.x < S::kSeg * kSegPrimMax) {
+    float h2, m2;
+    screen_thresholds(A, X, threadIdx.x / kSegPrimMax, threadIdx.x % kSegPrimMax, A.f32_delta, h2, m2);
+    L.thr[2 * threadIdx.x] = h2;
+    L.thr[2 * threadIdx.x + 1] = m2;
+  }
+  __syncthreads();
+
+  if constexpr (!REFINE) {
+    const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const bool in_range = gi < A.n;
+    screen_body<ROBOT, NL, EDGE, false>(A, M, X, obsf, sm, L, gi, in_range ? gi : (A.n - 1), in_range, t_entry);
+  } else {
+    // (no block-level synchronisation in the body: every wave works on its own slots of the shared arrays)
+    const unsigned list_count = *A.refine_count;
+#pragma unroll 1
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kBlock; base < list_count; base += static_cast<uint64_t>(gridDim.x) * kBlock) {
+      const uint64_t slot = base + threadIdx.x;
+      const bool in_range = slot < list_count;
+      const uint64_t gi = A.refine_list[in_range ? slot : list_count - 1];
+      screen_body<ROBOT, NL, EDGE, true>(A, M, X, obsf, sm, L, gi, gi, in_range, t_entry);
+    }
+  }
+}
+
+// fp32 variant of the flag path, screen stage: walk 1 and the frames of walk 2 in fp32.  Stability verdicts are
+// taken only where the fp32 error bounds allow it (model_update_f32); the other states go to the refine list for
+// screen_kernel<..., REFINE>.  The collision screen is the same fp32 classification with thresholds padded by the
+// frame walk's error bound; its undecided pairs go to the exact stage with a record that holds the joint ANGLES
+// (tagged), of which the exact stage takes the fp64 cos/sin itself.
+#ifndef MVK_SCREEN32_WAVES
+#define MVK_SCREEN32_WAVES 3
+#endif
+template <int ROBOT, int NL, bool EDGE>
+__global__ void __launch_bounds__(kBlock, MVK_SCREEN32_WAVES)
+screen32_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                const DevObsF* __restrict__ obsf) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ float sm_csf[2 * NJ * kBlock];
+  __shared__ unsigned sm_ring[(kBlock / 64) * kRingWords * kRing];
+  __shared__ unsigned sm_res[kBlock];
+  __shared__ float sm_thr[S::kSeg * kSegPrimMax * 2];
+  lds_float* csf = (lds_float*)sm_csf;
+  const ScreenLds L{(lds_uint*)sm_ring + (threadIdx.x >> 6) * (kRingWords * kRing), (lds_uint*)sm_res + (threadIdx.x & ~63), (lds_float*)sm_thr};
+  if (threadIdx.x < S::kSeg * kSegPrimMax) {
+    float h2, m2;
+    screen_thresholds(A, X, threadIdx.x / kSegPrimMax, threadIdx.x % kSegPrimMax, A.f32_delta_fk, h2, m2);
+    L.thr[2 * threadIdx.x] = h2;
+    L.thr[2 * threadIdx.x + 1] = m2;
+  }
+  __syncthreads();
+
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+  if (gi < static_cast<uint64_t>(S::kSeg * kQueueShards) || gi == static_cast<uint64_t>(kRefineSlot))
+    A.queue_count_next[gi * kQueueCounterPitch] = 0u;
+
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, EDGE, true>(A, li, st, edge, step);
+  double Rw[9];
+  quat_to_mat(st[3], st[4], st[5], st[6], Rw);
+  bool finite = true;
+#pragma unroll
+  for (int k = 0; k < 7 + NJ; ++k) finite = finite && isfinite(st[k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) finite = finite && isfinite(Rw[k]);
+  float Rf[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rf[k] = static_cast<float>(Rw[k]);
+
+  int cls = 1;  // 1 stable (or not asked), 0 unstable, -1 uncertain
+  if (A.do_stab) {
+    float dbg[3];
+    cls = model_update_f32<ROBOT, NL>(A, X, st, Rf, csf, A.fc_t_min ? dbg : nullptr);
+    if (A.fc_t_min && in_range) {  // diagnostics (mvk_debug_f32_bounds): smallest s - e, smallest s + e, class
+      A.fc_t_min[gi] = dbg[0];
+      A.fc_rp_min[gi] = dbg[1];
+      A.rp_margin[gi] = finite ? static_cast<double>(cls) : -2.0;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float sj, cj;
+      sincos_f32(static_cast<float>(st[7 + j]), sj, cj);
+      csf[(2 * j) * kBlock + threadIdx.x] = cj;
+      csf[(2 * j + 1) * kBlock + threadIdx.x] = sj;
+    }
+  }
+  const bool need_coll = A.do_coll && A.n_obs > 0;
+  const bool f32_safe = fmax(fabs(st[0]), fmax(fabs(st[1]), fabs(st[2]))) + X->reach <= A.f32_range;
+  // refined in fp64: stability the bounds cannot decide; states whose collision screen fp32 cannot be trusted with
+  const bool refine = in_range && finite && cls != 0 && (cls < 0 || (need_coll && !f32_safe));
+  const bool live = finite && need_coll && cls == 1 && f32_safe;
+  bool hit = false;
+  unsigned segmask = 0u;
+  if (__any(live)) collide_screen_f32<ROBOT, NL>(A, X, obsf, st, Rf, csf, L, live, hit, segmask);
+  const bool undecided = in_range && live && !hit && segmask != 0u;
+  {
+    const unsigned todo = undecided ? segmask : 0u;
+    if (__any(todo != 0u)) {
+      enqueue_undecided<ROBOT, NL, false>(A, gi, todo);
+      if (todo != 0u) {  // record with the joint angles (tag 1 in the pad slot)
+        double2* __restrict__ dst = reinterpret_cast<double2*>(A.queue_rec + gi * S::kRecPad);
+        dst[0] = make_double2(st[0], st[1]);
+        dst[1] = make_double2(st[2], st[3]);
+        dst[2] = make_double2(st[4], st[5]);
+        dst[3] = make_double2(st[6], 1.0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) dst[4 + j] = make_double2(st[7 + j], 0.0);
+      }
+    }
+  }
+  {
+    const unsigned long long bal = __ballot(refine);
+    if (bal) {
+      const int lane = threadIdx.x & 63;
+      const int leader = __ffsll(static_cast<long long>(bal)) - 1;
+      unsigned at = 0;
+      if (lane == leader) at = atomicAdd(A.refine_count, static_cast<unsigned>(__popcll(bal)));
+      at = __shfl(at, leader) + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)));
+      if (refine) A.refine_list[at] = static_cast<uint32_t>(gi);
+    }
+  }
+  const bool valid = finite && cls != 0 && !hit;  // (a refined state: valid so far)
+  if (!EDGE) {
+    if (in_range) {
+      if (A.flags) A.flags[gi] = valid ? 1 : 0;
+      if (A.band) A.band[gi] = finite ? 0 : 1;
+    }
+    if (A.mask) {
+      const unsigned long long bal = __ballot(in_range && valid);
+      if ((threadIdx.x & 63) == 0 && (gi - (gi & 63)) < A.n) A.mask[gi >> 6] = bal;
+    }
+  } else {
+    if (in_range && !valid) atomicMin(&A.first_invalid[edge], step);
+    if (A.band && in_range && !finite) A.band[edge] = 1;
+  }
 }
 
 template <int ROBOT, int NL, bool EDGE>
@@ -2068,10 +2719,12 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       const double2* __restrict__ rec = reinterpret_cast<const double2*>(A.queue_rec + gi * S::kRecPad);
       const double2 v0 = rec[0], v1 = rec[1], v2 = rec[2], v3 = rec[3];
       st[0] = v0.x; st[1] = v0.y; st[2] = v1.x; st[3] = v1.y; st[4] = v2.x; st[5] = v2.y; st[6] = v3.x;
+      const bool angles = v3.y != 0.0;  // record of the fp32 screen: joint angles, the cos/sin are taken here in fp64
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         if (j < ks) {  // the frame of segment ks turns on joints 0 .. ks-1 only
-          const double2 v = rec[4 + j];
+          double2 v = rec[4 + j];
+          if (angles) sincos_cw(v.x, v.y, v.x);
           sm.cs[(2 * j) * kBlock + tid] = v.x;
           sm.cs[(2 * j + 1) * kBlock + tid] = v.y;
         }
@@ -2335,7 +2988,7 @@ model_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 // Occupancy over registers: the walks wait on dependent gathers, so the kernel is compiled for kDistanceWaves waves
 // per SIMD and its LDS (candidate lists, first-walk bounds, the wave's exact-distance batch) is sized to allow them.
 #ifndef MVK_DISTANCE_WAVES
-#define MVK_DISTANCE_WAVES 3
+#define MVK_DISTANCE_WAVES 2
 #endif
 constexpr int kDistanceWaves = MVK_DISTANCE_WAVES;
 template <int ROBOT, int NL>
@@ -2791,12 +3444,23 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s, hipEvent_t* e
   // exact stage: as many blocks as the chip holds at once stride over the chunks of all queues
   const uint64_t chunks_max = blocks * Shape<ROBOT, NL>::kSeg, resident = a.exact_blocks ? a.exact_blocks : 768;
   dim3 g2(static_cast<unsigned>(chunks_max < resident ? chunks_max : resident));
+  dim3 g3(a.refine_blocks ? a.refine_blocks : 1u);
   if (edge_mode) {
-    hipLaunchKernelGGL((screen_kernel<ROBOT, NL, true>), g, b, 0, s, a, a.model, a.extras, a.obsf);
+    if (a.f32_walk) {
+      hipLaunchKernelGGL((screen32_kernel<ROBOT, NL, true>), g, b, 0, s, a, a.model, a.extras, a.obsf);
+      hipLaunchKernelGGL((screen_kernel<ROBOT, NL, true, true>), g3, b, 0, s, a, a.model, a.extras, a.obsf);
+    } else {
+      hipLaunchKernelGGL((screen_kernel<ROBOT, NL, true, false>), g, b, 0, s, a, a.model, a.extras, a.obsf);
+    }
     if (ev) (void)hipEventRecord(ev[1], s);
     if (a.do_coll && a.n_obs > 0) hipLaunchKernelGGL((exact_kernel<ROBOT, NL, true>), g2, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
   } else {
-    hipLaunchKernelGGL((screen_kernel<ROBOT, NL, false>), g, b, 0, s, a, a.model, a.extras, a.obsf);
+    if (a.f32_walk) {
+      hipLaunchKernelGGL((screen32_kernel<ROBOT, NL, false>), g, b, 0, s, a, a.model, a.extras, a.obsf);
+      hipLaunchKernelGGL((screen_kernel<ROBOT, NL, false, true>), g3, b, 0, s, a, a.model, a.extras, a.obsf);
+    } else {
+      hipLaunchKernelGGL((screen_kernel<ROBOT, NL, false, false>), g, b, 0, s, a, a.model, a.extras, a.obsf);
+    }
     if (ev) (void)hipEventRecord(ev[1], s);
     if (a.do_coll && a.n_obs > 0) hipLaunchKernelGGL((exact_kernel<ROBOT, NL, false>), g2, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
   }

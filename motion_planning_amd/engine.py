@@ -169,6 +169,15 @@ class Engine:
         _check(self.lib, self.lib.mvk_set_params(self.ctx, C.byref(params)))
         self.params = params
 
+    def set_flag_precision(self, precision):
+        """A.PRECISION_F64 (default) or A.PRECISION_F32_REFINED: arithmetic of the flag path (include/mvk.h)"""
+        _check(self.lib, self.lib.mvk_set_flag_precision(self.ctx, int(precision)))
+
+    def last_refined_count(self):
+        v = C.c_uint64()
+        _check(self.lib, self.lib.mvk_last_refined_count(self.ctx, C.byref(v)))
+        return int(v.value)
+
     def set_profiling(self, enable=True):
         _check(self.lib, self.lib.mvk_set_profiling(self.ctx, int(enable)))
 
