@@ -6,6 +6,7 @@
 // device is usable every compute entry point returns MVK_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -91,6 +92,10 @@ void quat_to_rows(const double q[4], double R[9]) {
 
 using namespace mvk;
 
+namespace mvk {
+int edges_submit_two_launches(mvk_ctx* c);
+}
+
 struct mvk_ctx {
   int device = 0;
   mvk_model model{};
@@ -107,7 +112,18 @@ struct mvk_ctx {
   int flag_precision = MVK_PRECISION_F64;  // mvk_set_flag_precision
   float f32_delta_fk = 0.0f;
   float f32_bound_scale = 1.0f;
-  const uint32_t* last_refine_counter = nullptr;  // device address of the last fp32-variant call's refine counter
+  const uint32_t* last_refine_counter = nullptr;
+  // small host batches in one launch (fused_kernel): a pinned control block holding the done word the kernel
+  // raises, the 16-bit call sequence, the per-edge tag array, and what the last fused call still owes the caller
+  PinBuf pin_ctl;
+  Buf first_tag;
+  uint32_t fused_seq = 0;
+  bool fused_enabled = true;
+  bool fused_in_flight = false;   // (edge checks begun with _begin)
+  size_t edges_n = 0, edges_dld = 0, edges_blob_bytes = 0;
+  uint64_t edges_total = 0;
+  bool edges_have_nd = false;
+  int32_t edges_nu = 1;  // device address of the last fp32-variant call's refine counter
   uint64_t call_index = 0;
   int n_cu = 256;
   // mvk_check_motion_batch_begin / _end
@@ -508,6 +524,52 @@ int leave_stream(mvk_ctx* c, hipStream_t s) {
   return MVK_OK;
 }
 
+// ---- small host batches: one launch, no copies (fused_kernel) --------------------------------------------------
+// eligible: flag path in fp64, at most kFusedMaxBlocks blocks of lanes (all resident at once)
+bool fused_eligible(const mvk_ctx* c, uint64_t lanes) {
+  return c->fused_enabled && c->flag_precision == MVK_PRECISION_F64 && lanes > 0 &&
+         lanes <= static_cast<uint64_t>(kFusedMaxBlocks) * kBlock;
+}
+// after prepare_queue: the barrier / completion counters of this call's set, the next sequence number, the done word
+int fused_arm(mvk_ctx* c, EvalArgs& a, hipStream_t s, size_t n_edges) {
+  a.fused = 1;
+  a.fused_bar = a.queue_count + static_cast<size_t>(MVK_MAX_SEG * kQueueShards - 2) * kQueueCounterPitch;
+  a.fused_done = a.queue_count + static_cast<size_t>(MVK_MAX_SEG * kQueueShards - 3) * kQueueCounterPitch;
+  c->fused_seq = c->fused_seq >= 0xFFFFu ? 1u : c->fused_seq + 1u;
+  a.fused_seq = c->fused_seq;
+  a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
+  if (n_edges) {
+    const size_t before = c->first_tag.cap;
+    if (int rc = c->first_tag.reserve(n_edges * sizeof(uint32_t))) return rc;
+    // tags of an older call lose against this call's sequence number -- except after the 16-bit number has wrapped
+    // (or in fresh memory): then the array is cleared once
+    if (c->fused_seq == 1u || c->first_tag.cap != before) HIP_TRY(hipMemsetAsync(c->first_tag.p, 0, c->first_tag.cap, s));
+    a.first_tag = static_cast<uint32_t*>(c->first_tag.p);
+  }
+  return MVK_OK;
+}
+// waits for the done word of call `seq`: a short poll (the kernel raises it from the device), then the stream.
+// returns 1 when the kernel's grid barrier gave up (the caller repeats the call with two launches)
+int fused_wait(mvk_ctx* c, uint32_t seq, hipStream_t s, int* gave_up) {
+  volatile uint32_t* done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
+  *gave_up = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    const uint32_t v = __atomic_load_n(const_cast<const uint32_t*>(const_cast<uint32_t*>(done)), __ATOMIC_ACQUIRE);
+    if ((v & 0x7FFFFFFFu) == seq) {
+      if (v & 0x80000000u) { *gave_up = 1; HIP_TRY(hipStreamSynchronize(s)); }
+      return MVK_OK;
+    }
+    __builtin_ia32_pause();
+    if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+  }
+  HIP_TRY(hipStreamSynchronize(s));  // a long kernel (or a busy GPU): let the runtime wait
+  const uint32_t v = *done;
+  if ((v & 0x7FFFFFFFu) != seq) return fail(MVK_ERR_HIP, "fused flag path: the kernel finished without raising its done word");
+  *gave_up = (v & 0x80000000u) ? 1 : 0;
+  return MVK_OK;
+}
+
 // flag path: size the hand-off buffers between the screen stage and the exact stage for n lanes and
 // hand this call its set of counters
 int prepare_queue(mvk_ctx* c, EvalArgs& a, uint64_t n) {
@@ -696,6 +758,12 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
     return nullptr;
   }
   if ((e = hipMemset(c->queue_counts.p, 0, 2 * mvk_ctx::kQueueCounterSet * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(queue counters)", e);
+  if (c->pin_ctl.reserve(4096) != MVK_OK) {
+    mvk_destroy(c);
+    return nullptr;
+  }
+  std::memset(c->pin_ctl.p, 0, 4096);
+  if (const char* off = std::getenv("MVK_NO_FUSED")) c->fused_enabled = off[0] != '1';  // diagnostics: always two launches
   return c;
 }
 
@@ -717,8 +785,10 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
                 &c->partial, &c->stats_out, &c->full_rec, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
   for (Buf* b : all) b->release();
   c->edge_blob.release();
+  c->first_tag.release();
   c->pin_up.release();
   c->pin_down.release();
+  c->pin_ctl.release();
   delete c;
 }
 
@@ -958,6 +1028,42 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
   // Small batches (down to the single state of an OMPL isValid call, or the few hundred states of a densified
   // path) are shaped for latency like the edge checks: the rows packed into one pinned block, the outputs gathered
   // in another, every copy asynchronous, one synchronisation.  Large ones copy straight from / to the caller's memory.
+  // Flag-only requests of at most kFusedMaxBlocks blocks (a single isValid, a densified path): ONE launch that reads
+  // the rows from, and writes the verdicts to, pinned host memory and raises a done word there -- no copy, no
+  // stream synchronisation (fused_kernel).
+  if (flags && !min_dist && !margin && !band && !det && !force_full && fused_eligible(c, n)) {
+    if (int rc = c->pin_up.reserve(dld * rows * sizeof(double))) return rc;
+    if (int rc = c->pin_down.reserve(dld)) return rc;
+    double* up = static_cast<double*>(c->pin_up.p);
+    for (int r = 0; r < rows; ++r) std::memcpy(up + static_cast<size_t>(r) * dld, soa + static_cast<size_t>(r) * ld, n * sizeof(double));
+    EvalArgs a;
+    base_args(c, a);
+    a.soa = up;  // a few states: the kernel reads the pinned rows itself; more: one copy up first
+    if (n > 1024) {
+      HIP_TRY(hipMemcpyAsync(c->in_a.p, up, dld * rows * sizeof(double), hipMemcpyHostToDevice, s));
+      a.soa = static_cast<const double*>(c->in_a.p);
+    }
+    a.n = n;
+    a.ld = dld;
+    a.layout = layout;
+    if (int rc = c->flags.reserve(dld)) return rc;
+    a.flags = static_cast<uint8_t*>(c->flags.p);
+    a.host_flags = static_cast<uint8_t*>(c->pin_down.p);
+    c->stats_valid = false;
+    if (int rc = prepare_queue(c, a, n)) return rc;
+    if (int rc = fused_arm(c, a, s, 0)) return rc;
+    const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s, c->profiling ? c->ev : nullptr);
+    c->timed = c->profiling;
+    if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+    if (int rc = leave_stream(c, s)) return rc;
+    int gave_up = 0;
+    if (int rc = fused_wait(c, a.fused_seq, s, &gave_up)) return rc;
+    if (!gave_up) {
+      std::memcpy(flags, c->pin_down.p, n);
+      return MVK_OK;
+    }
+    // (the grid barrier gave up: never seen; the two-launch path below repeats the call)
+  }
   const bool staged = n <= (1u << 16);
   if (staged) {
     if (int rc = c->pin_up.reserve(dld * rows * sizeof(double))) return rc;
@@ -1167,7 +1273,7 @@ namespace {
 int run_edges_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_edges, size_t ld,
                   const int32_t* d_nd, const int64_t* d_edge_off, uint64_t total, int32_t nd_uniform,
                   uint8_t* d_ok, int32_t* d_first, hipStream_t s, bool first_is_initialised = false,
-                  const uint32_t* d_edge_block = nullptr) {
+                  const uint32_t* d_edge_block = nullptr, int32_t* fused_host_first = nullptr) {
   EvalArgs a;
   base_args(c, a);
   a.edge_block = d_edge_block;
@@ -1184,6 +1290,15 @@ int run_edges_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_e
   c->stats_valid = false;
   if (int rc = prepare_queue(c, a, total)) return rc;
   if (int rc = enter_stream(c, s)) return rc;
+  if (fused_host_first) {  // one launch; the arrays are pinned host memory the kernel reads and writes directly
+    if (int rc = fused_arm(c, a, s, n_edges)) return rc;
+    a.host_first = fused_host_first;
+    a.first_invalid = nullptr;
+    const int ef = launch_eval(a, c->model.robot_type, c->model.n_rotor, true, s, c->profiling ? c->ev : nullptr);
+    c->timed = c->profiling;
+    if (ef != hipSuccess) return fail(MVK_ERR_HIP, "edge kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(ef)));
+    return leave_stream(c, s);
+  }
   int e = first_is_initialised ? static_cast<int>(hipSuccess) : launch_edge_init(d_first, d_nd, a.nd_uniform, n_edges, s);
   if (e == hipSuccess) e = launch_eval(a, c->model.robot_type, c->model.n_rotor, true, s, c->profiling ? c->ev : nullptr);
   c->timed = c->profiling;
@@ -1254,6 +1369,7 @@ extern "C" int mvk_check_motion_batch_begin(mvk_ctx* c, const double* s1, const 
   // the verdict comes back with one copy (ok is derived from first_invalid on the host).
   const size_t rows = static_cast<size_t>(space_dim(&c->params, c->model.n_joint));
   const size_t dld = round_up(n_edges, 64);
+  c->edges_n = n_edges;
   size_t steps_max = 0;  // upper bound of the lane count, for the size of the per-block hints
   if (nd) for (size_t e = 0; e < n_edges; ++e) steps_max += static_cast<size_t>(nd[e] < 1 ? 1 : nd[e]);
   const size_t n_blk = nd ? (steps_max + kBlock - 1) / kBlock : 0;
@@ -1291,6 +1407,46 @@ extern "C" int mvk_check_motion_batch_begin(mvk_ctx* c, const double* s1, const 
       hblk[b] = static_cast<uint32_t>(e);
     }
   }
+  int32_t nd_max = nu;
+  if (nd) for (size_t e = 0; e < n_edges; ++e) nd_max = std::max(nd_max, hnd[e]);
+  c->fused_in_flight = false;
+  c->edges_blob_bytes = bytes;
+  c->edges_total = total;
+  c->edges_have_nd = nd != nullptr;
+  c->edges_nu = nu;
+  c->edges_dld = dld;
+  if (fused_eligible(c, total) && nd_max < 0xFFFF) {
+    // one copy up (every lane of an edge reads the edge's rows: they belong in device memory, where the cache holds
+    // them), one launch; the kernel leaves first_invalid in the pinned answer block and raises the done word
+    char* dev = static_cast<char*>(c->edge_blob.p);
+    if (int rc = enter_stream(c, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(dev, up, bytes, hipMemcpyHostToDevice, s));
+    if (int rc = run_edges_dev(c, reinterpret_cast<const double*>(dev), reinterpret_cast<const double*>(dev + off_s2), n_edges, dld,
+                               nd ? reinterpret_cast<const int32_t*>(dev + off_nd) : nullptr,
+                               nd ? reinterpret_cast<const int64_t*>(dev + off_off) : nullptr, total, nu, nullptr, nullptr, s, true,
+                               nd ? reinterpret_cast<const uint32_t*>(dev + off_blk) : nullptr, static_cast<int32_t*>(c->pin_down.p)))
+      return rc;
+    c->fused_in_flight = true;
+    c->edges_in_flight = n_edges;
+    c->edges_nd_off = off_nd;
+    c->edges_pending = true;
+    return MVK_OK;
+  }
+  return edges_submit_two_launches(c);
+}
+
+// the two-launch form of an edge check whose pinned block is ready (mvk_check_motion_batch_begin; and _end when
+// the fused kernel's grid barrier gave up)
+int mvk::edges_submit_two_launches(mvk_ctx* c) {
+  hipStream_t s = c->stream;
+  const size_t n_edges = c->edges_n, dld = c->edges_dld, bytes = c->edges_blob_bytes;
+  const size_t rows = static_cast<size_t>(space_dim(&c->params, c->model.n_joint));
+  const size_t off_s2 = rows * dld * sizeof(double), off_off = 2 * off_s2, off_nd = off_off + dld * sizeof(int64_t),
+               off_first = off_nd + dld * sizeof(int32_t), off_blk = off_first + dld * sizeof(int32_t);
+  const bool nd = c->edges_have_nd;
+  const uint64_t total = c->edges_total;
+  const int32_t nu = c->edges_nu;
+  char* up = static_cast<char*>(c->pin_up.p);
   char* dev = static_cast<char*>(c->edge_blob.p);
   if (int rc = enter_stream(c, s)) return rc;
   HIP_TRY(hipMemcpyAsync(dev, up, bytes, hipMemcpyHostToDevice, s));
@@ -1315,7 +1471,18 @@ extern "C" int mvk_check_motion_batch_end(mvk_ctx* c, uint8_t* ok, int32_t* firs
   if (n_edges == 0) return MVK_OK;
   // wait first, whatever the arguments: once the ctx reads as idle nothing may still be using its pinned blocks
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->fused_in_flight) {
+    c->fused_in_flight = false;
+    int gave_up = 0;
+    if (int rc = fused_wait(c, c->fused_seq, c->stream, &gave_up)) return rc;
+    if (gave_up) {  // (never seen) repeat with two launches
+      if (int rc = edges_submit_two_launches(c)) return rc;
+      c->edges_pending = false;
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+  } else {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   if (!ok && !first_invalid) return fail(MVK_ERR_INVALID_ARG, "no output requested");
   const int32_t* down = static_cast<const int32_t*>(c->pin_down.p);
   const int32_t* hnd = reinterpret_cast<const int32_t*>(static_cast<const char*>(c->pin_up.p) + c->edges_nd_off);

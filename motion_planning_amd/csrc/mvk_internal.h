@@ -140,6 +140,16 @@ struct EvalArgs {
   uint32_t* refine_list;   // [n] state indices the fp32 screen hands to the fp64 screen
   uint32_t* refine_count;  // one counter in the call's counter set
   uint32_t refine_blocks;  // grid of the refine launch
+  // small batches, one launch (fused_kernel): grid barrier and completion counters in the call's counter set, the
+  // verdicts go straight to pinned host memory and a done word there tells the host (no copies, no stream sync)
+  int32_t fused;           // 1: launch fused_kernel
+  uint32_t fused_seq;      // this call's sequence number (16 bits used by first_tag)
+  uint32_t* fused_bar;     // arrivals at the grid barrier
+  uint32_t* fused_done;    // blocks that have finished
+  uint32_t* first_tag;     // edge mode: [n_edges] (seq << 16 | 0xFFFF - step), atomicMax: no initialisation needed
+  int32_t* host_first;     // edge mode: pinned host [n_edges] first_invalid, written by the last block
+  uint8_t* host_flags;     // state mode: pinned host copy of flags[n], written by the last block
+  volatile uint32_t* host_done;  // pinned host: seq when every verdict is in place, seq | 0x80000000: barrier timed out
   // outputs (nullable)
   uint8_t* flags;
   uint64_t* mask;
@@ -197,6 +207,7 @@ struct StatsPartial {
 constexpr int kBlock = 256;
 constexpr int kQueueShards = 8;         // queues per segment (MVK_MAX_SEG * kQueueShards counters per set)
 constexpr int kQueueCounterPitch = 64;  // uint32 words between two counters: one 256-byte line each
+constexpr int kFusedMaxBlocks = 96;     // fused_kernel: every block resident at once (fewer than CUs); measured gain up to ~80 blocks (profiles/latency.py)
 
 
 // ---- the no-allocation flag path (mvk_is_valid_mask_noalloc_dev) -------------------------------------------

@@ -2361,7 +2361,17 @@ DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t
 //                   instead of the whole chain).  Exact fp64 tests; a collision clears the state's flag / mask
 //                   bit (or lowers first_invalid of its edge).
 // Full path = full_kernel: exact minimum distance, margins, details and statistics, no early exit.
+// edge mode: step `step` of `edge` is invalid.  Standard path: atomicMin into first_invalid (initialised to nd + 1).
+// Fused path: atomicMax of (call sequence << 16 | 0xFFFF - step) into first_tag, which needs no initialisation --
+// whatever an earlier call left there carries an older sequence number and loses.
+DEV void mark_invalid_step(const EvalArgs& A, uint64_t edge, int step) {
+  if (A.first_tag) atomicMax(A.first_tag + edge, (A.fused_seq << 16) | (0xFFFFu - static_cast<unsigned>(step)));
+  else atomicMin(&A.first_invalid[edge], step);
+}
+
 constexpr int kRefineSlot = MVK_MAX_SEG * kQueueShards - 1;  // counter of the refine list, in each counter set
+constexpr int kBarrierSlot = MVK_MAX_SEG * kQueueShards - 2, kDoneSlot = MVK_MAX_SEG * kQueueShards - 3;  // fused_kernel
+static_assert(MVK_MAX_SEG * kQueueShards - 3 >= 64, "the queues' counters use the first 64 slots at most");
 
 // Hand the undecided (state, segment) pairs of a wave to the exact stage.  Wave by wave and without a block barrier:
 // lane k of the wave reserves the wave's share of segment k's queue with one atomic (the queues are split
@@ -2412,7 +2422,7 @@ DEV void screen_body(const EvalArgs& A, const mvk_model* __restrict__ M, const D
   constexpr int NJ = S::kJoint;
   (void)t_entry;
   // the counters the NEXT call on this ctx appends to
-  if (!REFINE && (gi < static_cast<uint64_t>(S::kSeg * kQueueShards) || gi == static_cast<uint64_t>(kRefineSlot)))
+  if (!REFINE && (gi < static_cast<uint64_t>(S::kSeg * kQueueShards) || (gi >= static_cast<uint64_t>(kDoneSlot) && gi <= static_cast<uint64_t>(kRefineSlot))))
     A.queue_count_next[gi * kQueueCounterPitch] = 0u;
 
   double st[7 + NJ];
@@ -2470,7 +2480,7 @@ DEV void screen_body(const EvalArgs& A, const mvk_model* __restrict__ M, const D
         if (A.flags) A.flags[gi] = 0;
         if (A.mask) atomicAnd(reinterpret_cast<unsigned long long*>(A.mask) + (gi >> 6), ~(1ull << (gi & 63)));
       } else {
-        atomicMin(&A.first_invalid[edge], step);
+        mark_invalid_step(A, edge, step);
       }
     }
   } else if (!EDGE) {
@@ -2483,7 +2493,7 @@ DEV void screen_body(const EvalArgs& A, const mvk_model* __restrict__ M, const D
       if ((threadIdx.x & 63) == 0 && (gi - (gi & 63)) < A.n) A.mask[gi >> 6] = bal;
     }
   } else {
-    if (in_range && !valid) atomicMin(&A.first_invalid[edge], step);
+    if (in_range && !valid) mark_invalid_step(A, edge, step);
     if (A.band && in_range && band) A.band[edge] = 1;
   }
 #ifdef MVK_PROFS
@@ -2565,7 +2575,7 @@ screen32_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
   const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool in_range = gi < A.n;
   const uint64_t li = in_range ? gi : (A.n - 1);
-  if (gi < static_cast<uint64_t>(S::kSeg * kQueueShards) || gi == static_cast<uint64_t>(kRefineSlot))
+  if (gi < static_cast<uint64_t>(S::kSeg * kQueueShards) || (gi >= static_cast<uint64_t>(kDoneSlot) && gi <= static_cast<uint64_t>(kRefineSlot)))
     A.queue_count_next[gi * kQueueCounterPitch] = 0u;
 
   double st[7 + NJ];
@@ -2647,24 +2657,34 @@ screen32_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
       if ((threadIdx.x & 63) == 0 && (gi - (gi & 63)) < A.n) A.mask[gi >> 6] = bal;
     }
   } else {
-    if (in_range && !valid) atomicMin(&A.first_invalid[edge], step);
+    if (in_range && !valid) mark_invalid_step(A, edge, step);
     if (A.band && in_range && !finite) A.band[edge] = 1;
   }
 }
 
-template <int ROBOT, int NL, bool EDGE>
-__global__ void __launch_bounds__(kBlock)
-exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
-             const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf) {
+// LDS of the exact stage: the joint cos/sin of the frame walk and, once every lane has its frame, the block's pair
+// list share one region (a); then the frames [12][kBlock], the list lengths, the verdict bytes, the chunk table
+template <int ROBOT, int NL>
+struct ExactLds {
   using S = Shape<ROBOT, NL>;
+  static constexpr size_t kCsBytes = sizeof(double) * 2 * S::kJoint * kBlock, kItemBytes = sizeof(unsigned) * kSegPrimMax * kItemCap;
+  static constexpr size_t kABytes = kCsBytes > kItemBytes ? kCsBytes : kItemBytes;
+  static constexpr size_t kFrameOff = kABytes, kNitemsOff = kFrameOff + sizeof(double) * 12 * kBlock,
+                          kHitOff = kNitemsOff + 16, kFirstOff = kHitOff + kBlock,
+                          kBytes = kFirstOff + sizeof(unsigned) * (S::kSeg * kQueueShards + 1 + 3);
+};
+
+template <int ROBOT, int NL, bool EDGE>
+DEV void exact_body(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                    const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf, unsigned char* lds) {
+  using S = Shape<ROBOT, NL>;
+  using E = ExactLds<ROBOT, NL>;
   constexpr int NJ = S::kJoint;
-  // LDS: the joint cos/sin of the frame walk and, once every lane has its frame, the block's pair
-  // list share one region; then the frames [12][kBlock], the list lengths and the verdict bytes
-  constexpr size_t kCsBytes = sizeof(double) * 2 * NJ * kBlock, kItemBytes = sizeof(unsigned) * kSegPrimMax * kItemCap;
-  __shared__ __align__(16) unsigned char sm_a[kCsBytes > kItemBytes ? kCsBytes : kItemBytes];
-  __shared__ double sm_frame_[12 * kBlock];
-  __shared__ unsigned sm_nitems[kSegPrimMax];
-  __shared__ unsigned char sm_hit[kBlock];
+  unsigned char* sm_a = lds;
+  double* sm_frame_ = reinterpret_cast<double*>(lds + E::kFrameOff);
+  unsigned* sm_nitems = reinterpret_cast<unsigned*>(lds + E::kNitemsOff);
+  unsigned char* sm_hit = lds + E::kHitOff;
+  unsigned* sm_first = reinterpret_cast<unsigned*>(lds + E::kFirstOff);
   Smem sm{(lds_double*)sm_a, nullptr};
   lds_uint* items = (lds_uint*)sm_a;
   lds_double* frames = (lds_double*)sm_frame_;
@@ -2678,7 +2698,6 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   // the grid strides over the chunks.  sm_first[q] = first chunk of queue q.
   constexpr int kQueues = S::kSeg * kQueueShards;
   static_assert(kQueues <= 64, "one wave scans the queue lengths");
-  __shared__ unsigned sm_first[kQueues + 1];
   if (tid < 64) {  // counters written by screen_kernel, the launch before on this stream
     const unsigned mine_chunks = tid < kQueues ? (A.queue_count[tid * kQueueCounterPitch] + kBlock - 1) / kBlock : 0u;
     unsigned incl = mine_chunks;
@@ -2720,13 +2739,22 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       const double2 v0 = rec[0], v1 = rec[1], v2 = rec[2], v3 = rec[3];
       st[0] = v0.x; st[1] = v0.y; st[2] = v1.x; st[3] = v1.y; st[4] = v2.x; st[5] = v2.y; st[6] = v3.x;
       const bool angles = v3.y != 0.0;  // record of the fp32 screen: joint angles, the cos/sin are taken here in fp64
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (j < ks) {  // the frame of segment ks turns on joints 0 .. ks-1 only
+      if (__any(angles)) {  // (rolled: one copy of the sincos code, and the frame of segment ks turns on joints 0 .. ks-1 only)
+#pragma unroll 1
+        for (int j = 0; j < ks && j < NJ; ++j) {
           double2 v = rec[4 + j];
           if (angles) sincos_cw(v.x, v.y, v.x);
           sm.cs[(2 * j) * kBlock + tid] = v.x;
           sm.cs[(2 * j + 1) * kBlock + tid] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (j < ks) {
+            const double2 v = rec[4 + j];
+            sm.cs[(2 * j) * kBlock + tid] = v.x;
+            sm.cs[(2 * j + 1) * kBlock + tid] = v.y;
+          }
         }
       }
     }
@@ -2845,7 +2873,7 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
         uint64_t edge;
         int step, nd_e;
         edge_step(A, gi, edge, step, nd_e);
-        atomicMin(&A.first_invalid[edge], step);
+        mark_invalid_step(A, edge, step);
       }
     }
   }
@@ -2853,6 +2881,101 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 #ifndef MVK_PROFS
   if (blockIdx.x < n_chunks) PROF_STAGE_FLUSH;
 #endif
+}
+
+template <int ROBOT, int NL, bool EDGE>
+__global__ void __launch_bounds__(kBlock, 3)  // three blocks per CU is also what the launcher sizes the grid for
+exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+             const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf) {
+  __shared__ __align__(16) unsigned char lds[ExactLds<ROBOT, NL>::kBytes];
+  exact_body<ROBOT, NL, EDGE>(A, M, X, obs, obsf, lds);
+}
+
+// ------------------------------------------------------------------------
+// small batches: the whole flag path in ONE launch
+// ------------------------------------------------------------------------
+// A planner iteration, a densified path, a single isValid call: a few thousand lanes at most, where the two launches,
+// the two copies and the stream synchronisation cost more than the arithmetic.  For batches of at most
+// kFusedMaxBlocks blocks -- every block resident at once, one per CU if need be -- screen and exact stage run in one
+// kernel around a grid barrier (an arrival counter in the call's counter set; the wait is bounded, a block that
+// gives up says so in the done word and the host falls back to the two launches).  Inputs are read from, verdicts
+// written to, pinned host memory directly; the last block to finish raises the done word the host polls.
+constexpr unsigned kFusedSpinLimit = 1u << 16;  // ~30 ms
+
+template <int ROBOT, int NL, bool EDGE>
+__global__ void __launch_bounds__(kBlock, (Shape<ROBOT, NL>::kScreenWaves))
+fused_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+             const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  constexpr size_t kCs = sizeof(double) * 2 * NJ * kBlock, kRingB = sizeof(unsigned) * (kBlock / 64) * kRingWords * kRing,
+                   kResB = sizeof(unsigned) * kBlock, kThrB = sizeof(float) * S::kSeg * kSegPrimMax * 2;
+  constexpr size_t kScreenBytes = kCs + kRingB + kResB + kThrB, kExactBytes = ExactLds<ROBOT, NL>::kBytes;
+  __shared__ __align__(16) unsigned char lds[kScreenBytes > kExactBytes ? kScreenBytes : kExactBytes];
+  __shared__ unsigned sm_go;
+  Smem sm{(lds_double*)lds, nullptr};
+  const ScreenLds L{(lds_uint*)(lds + kCs) + (threadIdx.x >> 6) * (kRingWords * kRing), (lds_uint*)(lds + kCs + kRingB) + (threadIdx.x & ~63),
+                    (lds_float*)(lds + kCs + kRingB + kResB)};
+  if (threadIdx.x < S::kSeg * kSegPrimMax) {
+    float h2, m2;
+    screen_thresholds(A, X, threadIdx.x / kSegPrimMax, threadIdx.x % kSegPrimMax, A.f32_delta, h2, m2);
+    L.thr[2 * threadIdx.x] = h2;
+    L.thr[2 * threadIdx.x + 1] = m2;
+  }
+  __syncthreads();
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in_range = gi < A.n;
+  screen_body<ROBOT, NL, EDGE, false>(A, M, X, obsf, sm, L, gi, in_range ? gi : (A.n - 1), in_range, 0ull);
+
+  const bool second = A.do_coll && A.n_obs > 0;
+  if (second) {
+    // ---- grid barrier: every queue entry and record is in place before any block reads them ----
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(A.fused_bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0, go = 1u;
+      while (__hip_atomic_load(A.fused_bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        __builtin_amdgcn_s_sleep(16);  // ~0.4 us between polls: a few hundred pollers must not crowd the arrivals out of the L2 channel
+        if (++spins > kFusedSpinLimit) { go = 0u; break; }
+      }
+      sm_go = go;
+    }
+    __syncthreads();
+    if (!sm_go) {  // (never seen; the host repeats the call with two launches)
+      if (threadIdx.x == 0) {
+        *A.host_done = A.fused_seq | 0x80000000u;
+        __threadfence_system();
+      }
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    exact_body<ROBOT, NL, EDGE>(A, M, X, obs, obsf, lds);
+  }
+  // ---- completion: the last block to get here hands the verdicts to the host ----
+  __syncthreads();
+  // (the verdicts live in device memory -- flags, or first_tag -- until here: device-scope ordering is enough for
+  // every block but the last, which alone pays for a system-scope release)
+  if (threadIdx.x == 0)
+    sm_go = __hip_atomic_fetch_add(A.fused_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!sm_go) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (EDGE) {
+    for (uint64_t e = threadIdx.x; e < A.n_edges; e += kBlock) {
+      const unsigned v = __hip_atomic_load(A.first_tag + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int nd_e = A.nd ? (A.nd[e] < 1 ? 1 : A.nd[e]) : A.nd_uniform;
+      A.host_first[e] = (v >> 16) == (A.fused_seq & 0xFFFFu) ? static_cast<int>(0xFFFFu - (v & 0xFFFFu)) : nd_e + 1;
+    }
+  } else {  // flags: device buffer -> pinned host block, 16 bytes per lane and step (both padded to 64 bytes)
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(A.flags);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(A.host_flags);
+    for (uint64_t i = threadIdx.x; i < (A.n + 15) / 16; i += kBlock) dst[i] = src[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();  // one system-scope release for the whole block (cumulative over the barrier)
+    *A.host_done = A.fused_seq;
+  }
 }
 
 // Full path = two launches on one stream: the statics want registers and have no gathers, the distance
@@ -3439,6 +3562,13 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s, hipEvent_t* e
     if (ev) (void)hipEventRecord(ev[1], s);
     if (a.full_rec) hipLaunchKernelGGL((distance_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras, a.obs);
     if (ev) (void)hipEventRecord(ev[2], s);
+    return hipGetLastError();
+  }
+  if (a.fused) {
+    if (blocks > static_cast<uint64_t>(kFusedMaxBlocks)) return hipErrorInvalidValue;
+    if (edge_mode) hipLaunchKernelGGL((fused_kernel<ROBOT, NL, true>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
+    else hipLaunchKernelGGL((fused_kernel<ROBOT, NL, false>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
+    if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
     return hipGetLastError();
   }
   // exact stage: as many blocks as the chip holds at once stride over the chunks of all queues

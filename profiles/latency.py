@@ -11,7 +11,7 @@ import motion_planning_amd as mp
 model, params, boxes, start, goal = common.config1()
 eng = mp.Engine(model, boxes, params)
 rng = np.random.default_rng(0)
-for E in (1, 64, 256, 1024):
+for E in ([int(x) for x in sys.argv[1:]] or [1, 64, 256, 1024]):
     s1 = np.tile(start[:, None], (1, E)) + rng.normal(scale=0.05, size=(6, E))
     s2 = s1 + rng.normal(scale=0.1, size=(6, E))
     nd = np.full(E, 41, np.int32)

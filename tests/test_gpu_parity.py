@@ -483,3 +483,64 @@ def test_full_size_c2_properties():
     assert changed.sum() <= 20, changed.sum()            # only samples within rounding of contact may flip
     assert np.all(np.abs(md.cpu().numpy()[changed]) < 1e-9)
     eng.close()
+
+
+def test_small_host_batches_one_launch_equals_two_launches(monkeypatch):
+    """Host calls of at most 96 blocks of lanes (24,576) run screen and exact stage in ONE launch around a grid barrier, reading and
+    writing pinned host memory directly (fused_kernel); MVK_NO_FUSED=1 keeps the two launches and the copies.  Same
+    verdicts both ways, state batches and edge batches, sizes around the block / grid limits, and against the oracle."""
+    w = common.config2k(n=70000)
+    ref = O.eval_batch(w.model, w.boxes, w.params, w.soa[:, :9000], w.layout, threads=8)
+    model, params, boxes, s1, s2, nd = common.config4(n_edges=3000)
+    sp = O.Space(params, model.n_joint)
+    nd_var = np.array([max(1, min(90, sp.valid_segment_count(s1[:, e], s2[:, e]))) for e in range(600)], np.int32)
+    out = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("MVK_NO_FUSED", "1")
+        eng = mp.Engine(w.model, w.boxes, w.params)
+        out[fused, "states"] = [eng.is_valid_batch(w.soa[:, :n], w.layout)["flags"] for n in (1, 2, 255, 256, 257, 9000, 24576, 24577, 70000)]
+        eng.close()
+        eng = mp.Engine(model, boxes, params)
+        out[fused, "edges"] = [eng.check_motion_batch(s1[:, :e], s2[:, :e], k) for e, k in ((1, 64), (37, 64), (1024, 64), (1025, 64), (3000, 7))]
+        out[fused, "edges"].append(eng.check_motion_batch(s1[:, :600], s2[:, :600], nd_var))
+        eng.check_motion_batch_begin(s1[:, :500], s2[:, :500], 64)
+        out[fused, "edges"].append(eng.check_motion_batch_end())
+        eng.close()
+    for a, b in zip(out[True, "states"], out[False, "states"]):
+        assert np.array_equal(a, b), len(a)
+    for (ok_a, first_a), (ok_b, first_b) in zip(out[True, "edges"], out[False, "edges"]):
+        assert np.array_equal(ok_a, ok_b) and np.array_equal(first_a, first_b), len(ok_a)
+    band = ref["band"].astype(bool)
+    assert not np.any((out[True, "states"][5] != ref["flags"]) & ~band)
+    g_ok, g_first, g_band = O.check_motion_batch(model, boxes, params, s1[:, :600], s2[:, :600], nd_var)
+    ok, first = out[True, "edges"][5]
+    clear = ~g_band.astype(bool)
+    assert np.array_equal(ok[clear], g_ok[clear]) and np.array_equal(first[clear], g_first[clear])
+
+
+def test_many_small_calls_in_a_row_keep_their_answers_apart():
+    """the fused path's call sequence number, alternating counter sets and tag array over a few hundred calls of
+    changing size on one context, states and edges interleaved"""
+    w = common.config2(n=4096)
+    ref = O.eval_batch(w.model, w.boxes, w.params, w.soa, w.layout, threads=8)
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    p4 = mp.default_params(w.model, A.MODE_JOINTS_AND_BASE, A.SE2)
+    rng = np.random.default_rng(1)
+    for it in range(300):
+        n = int(rng.integers(1, 700))
+        at = int(rng.integers(0, 4096 - n))
+        f = eng.is_valid_batch(w.soa[:, at:at + n], w.layout)["flags"]
+        bad = (f != ref["flags"][at:at + n]) & ~ref["band"][at:at + n].astype(bool)
+        assert not bad.any(), (it, n, at)
+    eng.close()
+    model, params, boxes, s1, s2, nd = common.config4(n_edges=512)
+    g_ok, g_first, g_band = O.check_motion_batch(model, boxes, params, s1, s2, nd)
+    eng = mp.Engine(model, boxes, params)
+    for it in range(200):
+        e = int(rng.integers(1, 200))
+        at = int(rng.integers(0, 512 - e))
+        ok, first = eng.check_motion_batch(s1[:, at:at + e], s2[:, at:at + e], nd)
+        clear = ~g_band[at:at + e].astype(bool)
+        assert np.array_equal(ok[clear], g_ok[at:at + e][clear]) and np.array_equal(first[clear], g_first[at:at + e][clear]), (it, e, at)
+    eng.close()
