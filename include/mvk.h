@@ -478,10 +478,16 @@ int mvk_cog_to_root(const mvk_model* model, const double* cog_state /*[7+J]*/, d
 /* ContinuousPathGenerator::discretePathResampling
  * (aerial_motion_planning_msgs/src/continuous_path_generator.cpp:119-230); parameters
  * resampling_angular_rate (1.0) and resampling_seg_diff_thresh (0.2) (:124-125).
- * States are row major [n][7+J]; returns the number of states written, negative on error.
- * discretePathSmoothing (:57-117) is not provided: its FIR filters are in an absent package. */
+ * States are row major [n][7+J]; returns the number of states written, negative on error. */
 int mvk_path_resample(const double* cog_states, int n, int n_joint, double angular_rate, double seg_diff_thresh,
                       double* out, int cap);
+/* ContinuousPathGenerator::discretePathSmoothing (continuous_path_generator.cpp:57-117): low-pass filter over the
+ * ROOT states of a path (root xyz + joints in one filter, root orientation in another, both of factor filter_rate,
+ * default 0.1 (:61); the filters start on the first state and the last state is repeated 1 / filter_rate times, so
+ * the output has n + floor(1 / filter_rate) states and ends on the last one).  PARITY UNPINNED: the filters themselves
+ * (FirFilter / FirFilterQuaternion of the external kalman_filter package) are absent; restated as a moving average
+ * over round(1 / filter_rate) inputs.  out == NULL: returns the number of states it would write. */
+int mvk_path_smooth(const double* states, int n, int n_joint, double filter_rate, double* out, int cap);
 /* ContinuousPathGenerator::calcContinuousPath (:232-282) + BsplineRos::initialize
  * (bspline_ros/src/bspline_ros.cpp:45-86): clamped uniform B-spline of `degree` (bspline_degree,
  * default 5) over [0, period] through the control points (cog xyz, roll pitch yaw with a

@@ -164,6 +164,7 @@ PROTOTYPES = {
     "mvk_path_densify": (ip, [PP, ip, vp, ip, vp, ip]),
     "mvk_root_to_cog": (ip, [PM, vp, vp]),
     "mvk_cog_to_root": (ip, [PM, vp, vp]),
+    "mvk_path_smooth": (ip, [vp, ip, ip, d, vp, ip]),
     "mvk_path_resample": (ip, [vp, ip, ip, d, d, vp, ip]),
     "mvk_spline_create": (vp, [vp, ip, ip, d, ip]),
     "mvk_spline_destroy": (None, [vp]),

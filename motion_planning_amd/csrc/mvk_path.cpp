@@ -11,9 +11,10 @@
 //   generateContinousEulerAngle                multilink_state.cpp:179-215
 // tf (Quaternion::angleShortestPath / slerp, Matrix3x3::getRPY) and tinyspline (clamped
 // uniform knots, de Boor evaluation, derive) are third-party and absent: their published
-// algorithms are restated.  discretePathSmoothing (:57-117) is NOT restated: its FirFilter /
-// FirFilterQuaternion live in the external kalman_filter package and nothing in the
-// reference pins their coefficients.
+// algorithms are restated.  discretePathSmoothing (:57-117) is restated from its call
+// parameters (mvk_path_smooth below); its FirFilter / FirFilterQuaternion live in the
+// external kalman_filter package and nothing in the reference pins their coefficients:
+// PARITY UNPINNED for that one function.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -140,6 +141,50 @@ extern "C" int mvk_cog_to_root(const mvk_model* m, const double* cog_state, doub
 
 // ContinuousPathGenerator::discretePathResampling (continuous_path_generator.cpp:119-230) on cog
 // states [n][7+J] (row major).  Returns the number of states written, negative on error.
+// ContinuousPathGenerator::discretePathSmoothing (continuous_path_generator.cpp:57-117).  PARITY UNPINNED: the
+// filters are kalman_filter's FirFilter(filter_rate, dim) / FirFilterQuaternion(filter_rate) (lpf_filter.h, package
+// absent from the reference tree and from this image).  What the call site fixes, and what is restated:
+//   * one filter over (root xyz, planned joints), one over the root orientation, both of factor filter_rate (0.1, :61)
+//   * both start filled with the first state (setInitValues, :76,:80)
+//   * the loop feeds the n states and then repeats the last one until index < n + 1 / filter_rate (:83-86): the
+//     output has n + floor(1 / filter_rate) states and ends ON the last state once the window holds nothing else
+//   * [UPSTREAM-RECOLLECTION] the filter is a moving average over the last round(1 / filter_rate) inputs; the
+//     quaternion one averages the sign-aligned quaternions of the window and renormalises
+// states: row major [n][7 + J] root states (what MultilinkState holds); returns the number of states written.
+extern "C" int mvk_path_smooth(const double* states, int n, int n_joint, double filter_rate, double* out, int cap) {
+  if (!states || n < 1 || n_joint < 0 || n_joint > MVK_MAX_JOINT) return fail(MVK_ERR_INVALID_ARG, "mvk_path_smooth: bad argument");
+  if (!(filter_rate > 0.0 && filter_rate <= 1.0)) return fail(MVK_ERR_INVALID_ARG, "mvk_path_smooth: filter_rate must be in (0, 1]");
+  const int w = 7 + n_joint;
+  const int window = std::max(1, static_cast<int>(std::lround(1.0 / filter_rate)));
+  const int total = n + static_cast<int>(std::floor(1.0 / filter_rate));
+  if (!out) return total;
+  if (cap < total) return fail(MVK_ERR_CAPACITY, "mvk_path_smooth: output holds %d states, %d needed", cap, total);
+  // ring of the last `window` inputs, all equal to the first state at the start
+  std::vector<double> ring(static_cast<size_t>(window) * w);
+  for (int k = 0; k < window; ++k) std::memcpy(&ring[static_cast<size_t>(k) * w], states, sizeof(double) * w);
+  for (int index = 0; index < total; ++index) {
+    const double* in = states + static_cast<size_t>(std::min(index, n - 1)) * w;
+    std::memcpy(&ring[static_cast<size_t>(index % window) * w], in, sizeof(double) * w);
+    double* o = out + static_cast<size_t>(index) * w;
+    for (int c = 0; c < w; ++c) o[c] = 0.0;
+    for (int k = 0; k < window; ++k) {
+      const double* r = &ring[static_cast<size_t>(k) * w];
+      // q and -q are the same attitude: align every quaternion of the window with the newest input
+      const double sgn = (r[3] * in[3] + r[4] * in[4] + r[5] * in[5] + r[6] * in[6]) < 0.0 ? -1.0 : 1.0;
+      for (int c = 0; c < 3; ++c) o[c] += r[c];
+      for (int c = 3; c < 7; ++c) o[c] += sgn * r[c];
+      for (int c = 7; c < w; ++c) o[c] += r[c];
+    }
+    const double inv = 1.0 / window;
+    for (int c = 0; c < 3; ++c) o[c] *= inv;
+    for (int c = 7; c < w; ++c) o[c] *= inv;
+    const double qn = std::sqrt(o[3] * o[3] + o[4] * o[4] + o[5] * o[5] + o[6] * o[6]);
+    if (!(qn > 0.0)) return fail(MVK_ERR_INVALID_ARG, "mvk_path_smooth: quaternions of state %d cancel out", index);
+    for (int c = 3; c < 7; ++c) o[c] /= qn;
+  }
+  return total;
+}
+
 extern "C" int mvk_path_resample(const double* cog_states, int n, int n_joint, double angular_rate,
                                  double seg_diff_thresh, double* out, int cap) {
   if (!cog_states || !out || n < 1 || n_joint < 0 || n_joint > MVK_MAX_JOINT) return fail(MVK_ERR_INVALID_ARG, "mvk_path_resample: bad argument");

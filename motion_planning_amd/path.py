@@ -27,6 +27,19 @@ def cog_to_root(model, state):
     return out
 
 
+def smooth(root_states, filter_rate=0.1):
+    """root_states: [n, 7+J].  ContinuousPathGenerator::discretePathSmoothing (parity unpinned, include/mvk.h)."""
+    lib = A.load()
+    s = np.ascontiguousarray(root_states, np.float64)
+    n, D = s.shape
+    m = lib.mvk_path_smooth(_p(s), n, D - 7, float(filter_rate), None, 0)
+    if m < 0:
+        _check(lib, m)
+    out = np.empty((m, D))
+    _check(lib, min(0, lib.mvk_path_smooth(_p(s), n, D - 7, float(filter_rate), _p(out), m)))
+    return out
+
+
 def resample(cog_states, angular_rate=1.0, seg_diff_thresh=0.2):
     """cog_states: [n, 7+J].  ContinuousPathGenerator::discretePathResampling."""
     lib = A.load()

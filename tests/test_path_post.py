@@ -163,3 +163,41 @@ def test_spline_matches_scipy_and_has_zero_end_velocity(degree):
     with pytest.raises(mp.MvkError):
         PP.Spline(path[:2], period, 5)  # control points <= degree (bspline_ros.cpp:47-51)
     sp.close()
+
+
+def test_path_smoothing_follows_what_the_call_site_fixes():
+    """discretePathSmoothing (continuous_path_generator.cpp:57-117).  PARITY UNPINNED: the FIR filters are in the absent
+    kalman_filter package; these are the properties the reference's own loop guarantees for any such filter, plus the
+    restated moving average against a numpy restatement."""
+    rng = np.random.default_rng(8)
+    J, n = 5, 37
+    path = _random_path(rng, n, J)
+    got = PP.smooth(path, 0.1)
+    assert got.shape == (n + 10, 7 + J)                    # n + 1 / filter_rate states (:83)
+    assert np.allclose(got[0], path[0])                    # the filters start on the first state (:76,:80)
+    assert np.allclose(got[-1, :3], path[-1, :3]) and np.allclose(got[-1, 7:], path[-1, 7:])   # and end on the last one
+    assert abs(abs(np.dot(got[-1, 3:7], path[-1, 3:7] / np.linalg.norm(path[-1, 3:7]))) - 1.0) < 1e-12
+    assert np.allclose(np.linalg.norm(got[:, 3:7], axis=1), 1.0)
+    # moving average over the last 10 inputs, numpy restatement
+    pad = np.vstack([np.repeat(path[:1], 9, axis=0), path, np.repeat(path[-1:], 10, axis=0)])
+    for k in range(n + 10):
+        win = pad[k:k + 10]
+        assert np.allclose(got[k, :3], win[:, :3].mean(0)) and np.allclose(got[k, 7:], win[:, 7:].mean(0))
+        q = win[:, 3:7] * np.where(win[:, 3:7] @ win[-1, 3:7] < 0, -1.0, 1.0)[:, None]
+        q = q.sum(0)
+        assert np.allclose(got[k, 3:7], q / np.linalg.norm(q))
+    # a constant path stays put; q and -q are the same attitude
+    const = np.repeat(path[:1], 8, axis=0)
+    assert np.allclose(PP.smooth(const, 0.25), np.repeat(path[:1] / np.array([1] * 3 + [np.linalg.norm(path[0, 3:7])] * 4 + [1] * J), 12, axis=0))
+    flipped = path.copy()
+    flipped[::2, 3:7] *= -1.0
+    a, b = PP.smooth(path, 0.1), PP.smooth(flipped, 0.1)
+    assert np.allclose(np.abs(np.sum(a[:, 3:7] * b[:, 3:7], axis=1)), 1.0)
+    # it smooths: the largest step of a noisy straight line shrinks
+    line = np.zeros((60, 7 + J))
+    line[:, 0] = np.linspace(0, 3, 60) + rng.normal(0, 0.02, 60)
+    line[:, 6] = 1.0
+    sm = PP.smooth(line, 0.1)
+    assert np.abs(np.diff(sm[:, 0], 2)).max() < 0.3 * np.abs(np.diff(line[:, 0], 2)).max()
+    with pytest.raises(mp.MvkError):
+        PP.smooth(path, 0.0)
