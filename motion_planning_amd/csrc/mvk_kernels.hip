@@ -3142,6 +3142,7 @@ distance_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
 
   double mind = INFINITY;
   if (__any(finite)) mind = collide_full<ROBOT, NL>(A, M, X, obs, st, Rw, sm, finite);
+  PROF_WAVE(28);
 
   const double margin = sc[static_cast<uint64_t>(kFullRecMargin) * A.full_rec_ld + gi];
   full_finish(A, gi, in_range, finite, margin, sc[static_cast<uint64_t>(kFullRecLamMin) * A.full_rec_ld + gi],
