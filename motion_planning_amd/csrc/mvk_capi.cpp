@@ -514,13 +514,22 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
 // Ordering of the calls that use the ctx's scratch buffers (see mvk_ctx::order_ev): a call on a stream other than
 // the last one's first makes its stream wait for the last call's work; every call leaves its own mark behind.
 int enter_stream(mvk_ctx* c, hipStream_t s) {
-  if (c->order_armed && s != c->order_stream) HIP_TRY(hipStreamWaitEvent(s, c->order_ev, 0));
+  if (c->order_armed && s != c->order_stream) {
+    // lazily: the mark is recorded on the previous call's stream only now, when a call on another stream needs
+    // it (it then covers everything that stream was given so far); calls that stay on one stream pay nothing
+    HIP_TRY(hipEventRecord(c->order_ev, c->order_stream));
+    HIP_TRY(hipStreamWaitEvent(s, c->order_ev, 0));
+  }
   return MVK_OK;
 }
 int leave_stream(mvk_ctx* c, hipStream_t s) {
-  HIP_TRY(hipEventRecord(c->order_ev, s));
   c->order_stream = s;
   c->order_armed = true;
+  return MVK_OK;
+}
+// host wait for the last call on the ctx, whatever stream it went to
+int wait_last_call(mvk_ctx* c) {
+  if (c->order_armed) HIP_TRY(hipStreamSynchronize(c->order_stream));
   return MVK_OK;
 }
 
@@ -770,7 +779,7 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
 extern "C" void mvk_destroy(mvk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->order_armed) (void)hipEventSynchronize(c->order_ev);  // the last call may be on a caller's stream
+  if (c->order_armed) (void)hipStreamSynchronize(c->order_stream);  // the last call may be on a caller's stream
   if (c->stream) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
@@ -832,7 +841,7 @@ extern "C" int mvk_last_refined_count(mvk_ctx* c, uint64_t* out) {
   if (!c || !out) return fail(MVK_ERR_INVALID_ARG, "null argument");
   if (!c->last_refine_counter) return fail(MVK_ERR_INVALID_ARG, "mvk_last_refined_count: no call with MVK_PRECISION_F32_REFINED yet");
   HIP_TRY(hipSetDevice(c->device));
-  if (c->order_armed) HIP_TRY(hipEventSynchronize(c->order_ev));  // the last call on this ctx, whatever its stream
+  if (int rc = wait_last_call(c)) return rc;  // the last call on this ctx, whatever its stream
   uint32_t v = 0;
   HIP_TRY(hipMemcpy(&v, c->last_refine_counter, sizeof(v), hipMemcpyDeviceToHost));
   *out = v;
