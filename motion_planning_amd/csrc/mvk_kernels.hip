@@ -478,6 +478,9 @@ struct Smem {
   // doubles), this lane's column gcs_col; nullptr: they are in `cs` (LDS)
   const double* gcs;
   uint64_t gcs_ld, gcs_col;
+  // full path, distance kernel: this wave's broadphase ring [kDRingWords][kRing] and its lanes' candidate counts [64]
+  lds_uint* dring;
+  lds_uint* dcnt;
 };
 constexpr int kUpperSlots = 16;
 constexpr int kExactBatch = 16;  // box pairs whose exact distance one wave computes together
@@ -1675,57 +1678,6 @@ DEV bool exact_pair(const mvk_model* __restrict__ M, const DevExtras* __restrict
 // ------------------------------------------------------------------------
 // Distance grid (mvk_capi.cpp, upload_distance_grid): the cell of a primitive's centre lists every box within
 // A.dgrid_radius of it.
-// grid_upper_bound: fp32 minimum of the centre's distance over the cell's list, padded by the fp32 error bound:
-// an upper bound of the primitive's distance (its origin lies inside it); +inf for an empty list.
-DEV double grid_upper_bound(const EvalArgs& A, bool on, const double pc[3]) {
-  const DevObsF* __restrict__ obsf = A.obsf;
-  unsigned gb, ge;
-  grid_cell(A.dgrid, pc, on, gb, ge);
-  const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
-  float best2f = INFINITY;
-#pragma unroll 1
-  for (unsigned g = gb; g < ge; ++g) {
-    const ushort4 v = *reinterpret_cast<const ushort4*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
-    const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < kGridGroup; ++e)
-      best2f = fminf(best2f, point_box_dist2_f32(obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]], x, y, z));
-  }
-  return static_cast<double>(sqrtf(best2f)) * 1.000001 + static_cast<double>(A.f32_delta);
-}
-
-// grid_collect: `bound` is an upper bound of the distance sought.  Only boxes whose centre distance is at most
-// thr = rb + max(bound, 0) can undercut it (lower bound: centre distance - bounding radius); when thr is within
-// the grid's radius the cell's list holds all of them: they join the lane's candidate list, in ascending box
-// order, and the function returns true ([gb, ge): the cell's groups, for a lane whose candidates overflow its
-// list).  Otherwise (far from every box, outside the grid volume, beyond the fp32 range: `on` false) nothing is listed.
-DEV bool grid_collect(const EvalArgs& A, const Smem& sm, bool on, const double pc[3], double rb, double bound, int& cnt,
-                      unsigned& gb, unsigned& ge) {
-  const int tid = threadIdx.x;
-  const DevObsF* __restrict__ obsf = A.obsf;
-  const double thr = rb + fmax(bound, 0.0);
-  gb = ge = 0;
-  if (!(on && thr + 2.0 * static_cast<double>(A.f32_delta) <= A.dgrid_radius)) return false;
-  grid_cell(A.dgrid, pc, on, gb, ge);
-  const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
-  const float tf = (static_cast<float>(thr) + A.f32_delta) * 1.000001f;
-  const float thr2f = tf * tf;
-#pragma unroll 1
-  for (unsigned g = gb; g < ge; ++g) {
-    const ushort4 v = *reinterpret_cast<const ushort4*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
-    const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < kGridGroup; ++e) {
-      const float l2 = point_box_dist2_f32(obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]], x, y, z);
-      if (ids[e] != kGridNone && l2 <= thr2f) {
-        if (cnt < kListCap) sm.list[cnt * kBlock + tid] = ids[e];
-        ++cnt;
-      }
-    }
-  }
-  return true;
-}
-
 // grid_collect_nearest: both steps in one pass over the cell's list, for the avoidance rows (no bound is known
 // beforehand there: the primitive's own nearest box sets it).  The threshold follows the running minimum, so the
 // list also keeps a few boxes met before the nearest one -- the drain's separating-axis gaps discard them.
@@ -1899,6 +1851,117 @@ DEV void sweep_for_lanes(const EvalArgs& A, const DevObs* __restrict__ obs, cons
 }
 
 // ------------------------------------------------------------------------
+// full path: broadphase shared out over the wave
+// ------------------------------------------------------------------------
+// A lane's scan of its primitive's cell list runs as long as the longest list among the 64 lanes, and a single lane
+// that needs the sweep over all boxes holds the whole wave for it.  As in the flag path's screen, the lanes therefore
+// PUSH what they need scanned -- (primitive centre, range of groups of kGridGroup boxes) -- into the wave's ring, and
+// the wave POPS the items one per lane: every lane tests one group of boxes for some lane's primitive, delivers the
+// result to that lane through LDS and pushes the rest of the range back.  A range is either a cell list of the
+// distance grid or ALL boxes of the scene in order (implicit ids), which is how the lanes the grid cannot answer are
+// served.  Two kinds of pop: the minimum squared centre distance (first walk: upper bounds), or the boxes within a
+// threshold appended to the source lane's candidate list (second walk).
+constexpr int kDRingWords = 6;  // centre xyz; first group | source lane | upper slot | all-boxes flag; end group; threshold
+
+template <bool COLLECT>
+DEV void dist_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const Smem& sm, unsigned& head, unsigned& qn) {
+  const int lane = threadIdx.x & 63, wave_tid = threadIdx.x - lane;
+  const unsigned m = qn < 64u ? qn : 64u;
+  // fewer items than lanes: every item is served by `rep` lanes, each taking another group of its range, so that a
+  // lone long range (a lane that needs ALL boxes) is walked 64 groups at a time instead of one
+  const unsigned rep = 64u / m;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const unsigned it = static_cast<unsigned>(lane) % m, sub = static_cast<unsigned>(lane) / m;
+  const bool active = sub < rep;
+  const unsigned at = (head + it) & (kRing - 1);
+  unsigned wa = 0, wb = 0, wt = 0;
+  float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+  if (active) {
+    cx = __uint_as_float(sm.dring[0 * kRing + at]);
+    cy = __uint_as_float(sm.dring[1 * kRing + at]);
+    cz = __uint_as_float(sm.dring[2 * kRing + at]);
+    wa = sm.dring[3 * kRing + at];
+    wb = sm.dring[4 * kRing + at];
+    wt = sm.dring[5 * kRing + at];
+  }
+  const unsigned g0 = wa & 0x1FFFFFu, src = (wa >> 21) & 63u, slot = (wa >> 27) & 15u;
+  const bool all = wa >> 31;
+  const unsigned g = g0 + sub;
+  if (active && g < wb) {
+    unsigned ids[kGridGroup];
+    if (all) {
+#pragma unroll
+      for (int e = 0; e < kGridGroup; ++e) {
+        const unsigned id = g * kGridGroup + e;
+        ids[e] = id < static_cast<unsigned>(A.n_obs) ? id : static_cast<unsigned>(kGridNone);
+      }
+    } else {
+      const uint2 w = *reinterpret_cast<const uint2*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
+      ids[0] = w.x & 0xFFFFu; ids[1] = w.x >> 16; ids[2] = w.y & 0xFFFFu; ids[3] = w.y >> 16;
+    }
+    DevObsF F[kGridGroup];
+#pragma unroll
+    for (int e = 0; e < kGridGroup; ++e) F[e] = obsf[ids[e] == kGridNone ? static_cast<unsigned>(A.n_obs) : ids[e]];
+    float l2[kGridGroup];
+#pragma unroll
+    for (int e = 0; e < kGridGroup; ++e) l2[e] = point_box_dist2_f32(F[e], cx, cy, cz);
+    if (COLLECT) {
+      const float thr2 = __uint_as_float(wt);
+#pragma unroll
+      for (int e = 0; e < kGridGroup; ++e)
+        if (ids[e] != kGridNone && l2[e] <= thr2) {
+          const unsigned at_list = __hip_atomic_fetch_add(sm.dcnt + src, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (at_list < static_cast<unsigned>(kListCap)) sm.list[at_list * kBlock + wave_tid + src] = static_cast<unsigned short>(ids[e]);
+        }
+    } else {
+      float mn = INFINITY;
+#pragma unroll
+      for (int e = 0; e < kGridGroup; ++e) mn = ids[e] != kGridNone ? fminf(mn, l2[e]) : mn;
+      // (non-negative floats order like their bit patterns)
+      __hip_atomic_fetch_min(reinterpret_cast<lds_uint*>(sm.upper) + slot * kBlock + wave_tid + src, __float_as_uint(mn), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  }
+  const bool more = active && sub == 0u && g0 + rep < wb;  // the item's owner lane puts the rest of the range back
+  head = (head + m) & (kRing - 1);
+  qn -= m;
+  const unsigned long long bal = __ballot(more);
+  if (bal) {
+    const unsigned to = (head + qn + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)))) & (kRing - 1);
+    if (more) {
+      sm.dring[0 * kRing + to] = __float_as_uint(cx);
+      sm.dring[1 * kRing + to] = __float_as_uint(cy);
+      sm.dring[2 * kRing + to] = __float_as_uint(cz);
+      sm.dring[3 * kRing + to] = wa + rep;  // (first group + rep < end: no carry into the tags)
+      sm.dring[4 * kRing + to] = wb;
+      sm.dring[5 * kRing + to] = wt;
+    }
+    qn += static_cast<unsigned>(__popcll(bal));
+  }
+}
+
+// one item per lane that wants one (wave-uniform head / qn)
+DEV void dist_push(const Smem& sm, bool want, const double pc[3], unsigned gb, unsigned ge, unsigned slot, bool all, float thr2,
+                   unsigned head, unsigned& qn) {
+  const int lane = threadIdx.x & 63;
+  const bool push = want && gb < ge;
+  const unsigned long long bal = __ballot(push);
+  if (bal) {
+    const unsigned to = (head + qn + static_cast<unsigned>(__popcll(bal & ((1ull << lane) - 1ull)))) & (kRing - 1);
+    if (push) {
+      sm.dring[0 * kRing + to] = __float_as_uint(static_cast<float>(pc[0]));
+      sm.dring[1 * kRing + to] = __float_as_uint(static_cast<float>(pc[1]));
+      sm.dring[2 * kRing + to] = __float_as_uint(static_cast<float>(pc[2]));
+      sm.dring[3 * kRing + to] = gb | (static_cast<unsigned>(lane) << 21) | (slot << 27) | (all ? 1u << 31 : 0u);
+      sm.dring[4 * kRing + to] = ge;
+      sm.dring[5 * kRing + to] = __float_as_uint(thr2);
+    }
+    qn += static_cast<unsigned>(__popcll(bal));
+  }
+}
+
+// ------------------------------------------------------------------------
 // full path: exact minimum distance over every (primitive, box) pair
 // ------------------------------------------------------------------------
 template <int ROBOT, int NL>
@@ -1921,20 +1984,48 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
   double upper = INFINITY;
   PROF_ACC_DECL;
   PROF_T0(t_w1);
+  const DevObsF* __restrict__ obsf = A.obsf;
+  const double delta = static_cast<double>(A.f32_delta), dd = 2.0 * delta;
+  const unsigned groups_all = static_cast<unsigned>((A.n_obs + kGridGroup - 1) / kGridGroup);
+  lds_uint* up_bits = reinterpret_cast<lds_uint*>(sm.upper);
+  unsigned head = 0, qn = 0;  // the wave's ring (wave-uniform)
   if (use_grid) {
+    const bool on = live && f32_safe;
+#pragma unroll
+    for (int sl = 0; sl < kUpperSlots; ++sl) up_bits[sl * kBlock + tid] = 0x7F800000u;  // +inf
+    double rb_max = 0.0;
+    // first walk: per primitive the smallest centre distance over its cell's list (fp32), through the ring
+    auto upper_walk = [&](bool all_boxes, bool who) {  // (all_boxes: kept for experiments; the walk below uses the lists)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = Rw[k];
+      p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
 #pragma unroll 1
-    for (int k = 0; k < S::kSeg; ++k) {
-      if (k > 0) advance_frame(M, sm, tid, k, R, p);
-      const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
+      for (int k = 0; k < S::kSeg; ++k) {
+        if (k > 0) advance_frame(M, sm, tid, k, R, p);
+        const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
 #pragma unroll 1
-      for (int qi = pb; qi < pe; ++qi) {
-        double pc[3];
-        prim_pose<S::kGimbal, false>(M, X->prim_order[qi], R, p, pc, nullptr);
-        const double up = grid_upper_bound(A, live && f32_safe, pc);
-        if (qi < kUpperSlots) sm.upper[qi * kBlock + tid] = static_cast<float>(up) * 0.999999f;  // rounded down
-        upper = fmin(upper, up);
+        for (int qi = pb; qi < pe; ++qi) {
+          const int q = X->prim_order[qi];
+          double pc[3];
+          prim_pose<S::kGimbal, false>(M, q, R, p, pc, nullptr);
+          rb_max = fmax(rb_max, X->prim_bound[q]);
+          unsigned gb = 0, ge = groups_all;
+          if (!all_boxes) grid_cell(A.dgrid, pc, who, gb, ge);
+          dist_push(sm, who, pc, gb, ge, static_cast<unsigned>(qi < kUpperSlots ? qi : kUpperSlots - 1), all_boxes, 0.0f, head, qn);
+#pragma unroll 1
+          while (qn >= 64u) dist_pop<false>(A, obsf, sm, head, qn);
+        }
       }
-    }
+#pragma unroll 1
+      while (qn > 0u) dist_pop<false>(A, obsf, sm, head, qn);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float u2 = INFINITY;
+#pragma unroll
+      for (int sl = 0; sl < kUpperSlots; ++sl) u2 = fminf(u2, __uint_as_float(up_bits[sl * kBlock + tid]));
+      return static_cast<double>(sqrtf(u2)) * 1.000001 + delta;  // an upper bound of the state's distance (+inf: nothing listed)
+    };
+    upper = upper_walk(false, on);
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = Rw[k];
     p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
@@ -1962,21 +2053,49 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       unsigned cell_b = 0, cell_e = 0;  // the grid cell's groups, when the candidates came from it
       if (use_grid) {
         const double bound = fmin(mind, upper);
-        // the first walk's minimum for this primitive: when even its nearest listed box is too far to undercut
-        // the bound (lower bound: centre distance - bounding radius), and the list is complete for that threshold,
-        // there is nothing to collect -- most primitives of a state, since only the few nearest matter
-        const double dd = 2.0 * static_cast<double>(A.f32_delta);
-        const double thr0 = rb + fmax(bound, 0.0);
-        const bool none = qi < kUpperSlots && live && f32_safe && thr0 + dd <= A.dgrid_radius &&
-                          static_cast<double>(sm.upper[qi * kBlock + tid]) - dd > thr0 + dd;
-        if (none) scan = false;
-        else if (grid_collect(A, sm, live && f32_safe, pc, rb, bound, cnt, cell_b, cell_e)) scan = false;
-        sweep_for_lanes_f32(A, sm, scan && f32_safe, pc, rb, bound, cnt);
-        const bool slow = scan && !f32_safe;
+        // the first walk's minimum for this primitive: when even its nearest box (of a list that is complete for the
+        // threshold) is too far to undercut the bound -- lower bound: centre distance - bounding radius -- there is
+        // nothing to collect: most primitives of a state, since only the few nearest matter
+        const bool on = live && f32_safe;
+        double thr0 = rb + fmax(bound, 0.0);
+        lds_uint* up_slot = up_bits + (qi < kUpperSlots ? qi : kUpperSlots - 1) * kBlock + tid;
+        double up_q = static_cast<double>(sqrtf(__uint_as_float(*up_slot))) * 0.999999;
+        // the cell's list holds every box within thr0 only when thr0 stays inside the grid's radius; a lane beyond
+        // that (the bound still loose, the robot far from every box, or outside the grid's volume) takes ALL boxes as
+        // its range: first their smallest centre distance, which tightens the bound, then the collection
+        const bool far = on && !(thr0 + dd <= A.dgrid_radius);
+        if (__any(far)) {
+          if (far) *up_slot = 0x7F800000u;
+          dist_push(sm, far, pc, 0u, groups_all, static_cast<unsigned>(qi < kUpperSlots ? qi : kUpperSlots - 1), true, 0.0f, head, qn);
+#pragma unroll 1
+          while (qn > 0u) dist_pop<false>(A, obsf, sm, head, qn);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (far) {
+            const double est = static_cast<double>(sqrtf(__uint_as_float(*up_slot)));
+            up_q = est * 0.999999;
+            upper = fmin(upper, est * 1.000001 + delta);
+            thr0 = rb + fmax(fmin(mind, upper), 0.0);
+          }
+        }
+        const bool none = (qi < kUpperSlots || far) && on && up_q - delta > thr0 + dd;
+        const bool want = on && !none;
+        const float tf = (static_cast<float>(thr0) + A.f32_delta) * 1.000001f;
+        sm.dcnt[lane] = 0u;
+        if (!far) grid_cell(A.dgrid, pc, want, cell_b, cell_e);
+        dist_push(sm, want, pc, far ? 0u : cell_b, far ? groups_all : cell_e, 0u, far, tf * tf, head, qn);
+#pragma unroll 1
+        while (qn > 0u) dist_pop<true>(A, obsf, sm, head, qn);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cnt = want ? static_cast<int>(sm.dcnt[lane]) : 0;
+        scan = on && far;  // (a list that overflows is then replaced by all boxes, not by the cell's list)
+        const bool slow = live && !f32_safe;  // beyond the fp32 coordinate range: the same in fp64, one lane at a time
         double b2 = INFINITY;
         int c2 = 0;
         sweep_for_lanes(A, obs, sm, slow, pc, rb, mind, b2, c2);
         if (slow) {
+          scan = true;
           if (sphere) mind = fmin(mind, sqrt(b2) - d0);  // exact for a sphere
           else cnt = c2;
         }
@@ -3124,12 +3243,15 @@ distance_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
   __shared__ double sm_ex_item[(kBlock / 64) * kExactBatch * kExactItem];
   __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kExactBatch];
   __shared__ float sm_upper[kUpperSlots * kBlock];
+  __shared__ unsigned sm_dring[(kBlock / 64) * kDRingWords * kRing];
+  __shared__ unsigned sm_dcnt[kBlock];
   const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool in_range = gi < A.n;
   const uint64_t li = in_range ? gi : (A.n - 1);
   Smem sm{nullptr, (lds_ushort*)sm_list, (lds_double*)sm_ex_item + (threadIdx.x >> 6) * kExactBatch * kExactItem,
           (lds_u64*)sm_ex_res + (threadIdx.x >> 6) * kExactBatch, nullptr, nullptr, (lds_float*)sm_upper,
-          A.full_rec, A.full_rec_ld, gi};   // (the record rows are written for every launched lane: gi, not li)
+          A.full_rec, A.full_rec_ld, gi,   // (the record rows are written for every launched lane: gi, not li)
+          (lds_uint*)sm_dring + (threadIdx.x >> 6) * (kDRingWords * kRing), (lds_uint*)sm_dcnt + (threadIdx.x & ~63)};
 
   double st[7 + NJ];
   uint64_t edge;

@@ -33,7 +33,7 @@ for off in ("0", "1"):
     print(f"flag path: screen {1e3 * k[0]:.0f} us + exact {1e3 * k[1]:.0f} us per {n} states = {n / (k[0] + k[1]) * 1e3:.3g} checks/s")
     eng.is_valid_batch_dev(d, w.layout, d_flags=fl, d_min_dist=md)
     torch.cuda.synchronize()
-    print(f"distance grid {'off' if off == '1' else 'on'}: mvk_create {1e3 * (t1 - t0):.0f} ms, full kernel {eng.last_kernel_ms()[0]:.2f} ms per {n} states, valid {int(fl.sum())}", flush=True)
+    print(f"distance grid {'off' if off == '1' else 'on'}: mvk_create {1e3 * (t1 - t0):.0f} ms, full path (model + distance kernel) {sum(eng.last_kernel_ms()):.2f} ms per {n} states, valid {int(fl.sum())}", flush=True)
     out.append(md.cpu().numpy())
     eng.close()
 print("identical distances:", np.array_equal(out[0], out[1]))
