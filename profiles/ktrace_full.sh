@@ -7,5 +7,5 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/ktfull_${TAG}_$W
 mkdir -p $OUT
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 $ROOT/profiles/full_time.py $W > $OUT/log.txt 2>&1 || { tail -5 $OUT/log.txt; exit 1; }
-cat $OUT/log.txt | grep full_kernel
+cat $OUT/log.txt | grep -E 'model_kernel|distance_kernel'
 python3 $ROOT/profiles/kstats.py $OUT

@@ -19,7 +19,7 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = ("screen_kernel", "exact_kernel", "full_kernel", "validity_kernel")
+KERNELS = ("screen32_kernel", "screen_kernel", "exact_kernel", "fused_kernel", "model_kernel", "distance_kernel", "avoid_kernel")
 
 
 def main():
@@ -41,6 +41,12 @@ def main():
         for (kn, k), v in sorted(acc.items()):
             mean[(kn, k)] = sum(v) / len(v)
             print(f"{kn} {k}: mean {sum(v)/len(v):.6g} over {len(v)} dispatches")
+    for kx in KERNELS:   # the utilisation figures VERDICT.md quotes, for every kernel the passes saw
+        if (kx, "SQ_ACTIVE_INST_VALU") in mean and (kx, "GRBM_GUI_ACTIVE") in mean and (kx, "SQ_WAVES") in mean:
+            busy = 4.0 * mean[(kx, "SQ_ACTIVE_INST_VALU")] / (mean[(kx, "GRBM_GUI_ACTIVE")] / 8.0 * 1024.0)
+            wait = mean.get((kx, "SQ_WAIT_ANY"), float("nan")) / mean[(kx, "SQ_WAVE_CYCLES")] if (kx, "SQ_WAVE_CYCLES") in mean else float("nan")
+            print(f"== {kx}: valu_busy {busy:.3f}, wait_any/wave_cycles {wait:.3f}, valu_insts_per_wave {mean[(kx, 'SQ_INSTS_VALU')] / mean[(kx, 'SQ_WAVES')]:.0f}, "
+                  f"vmem_insts_per_wave {mean.get((kx, 'SQ_INSTS_VMEM'), float('nan')) / mean[(kx, 'SQ_WAVES')]:.0f}, waves {mean[(kx, 'SQ_WAVES')]:.0f}")
     kn = "screen_kernel"
     if (kn, "FETCH_SIZE") in mean and (kn, "GRBM_GUI_ACTIVE") in mean:
         hbm = (2.0 * mean[(kn, "FETCH_SIZE")] + mean.get((kn, "WRITE_SIZE"), 0.0)) * 1024.0
