@@ -119,6 +119,11 @@ struct mvk_ctx {
   Buf first_tag;
   uint32_t fused_seq = 0;
   bool fused_enabled = true;
+  Buf small_done;                  // distance_small_kernel: blocks finished, over all polled calls (never reset)
+  uint32_t small_total = 0;        // ... and the count the last polled call ends on
+  bool tag_clear_needed = false;   // the call sequence number has wrapped since first_tag was last cleared
+  uint64_t small_full_max = kSmallFullMax;  // states per call up to which the full path takes distance_small_kernel
+  bool small_full_enabled = true;  // full path: distance_small_kernel for small batches (MVK_NO_SMALL_FULL=1: never)
   bool fused_in_flight = false;   // (edge checks begun with _begin)
   size_t edges_n = 0, edges_dld = 0, edges_blob_bytes = 0;
   uint64_t edges_total = 0;
@@ -503,6 +508,8 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
   a.grid = c->grid;
   a.dgrid = c->dgrid[0];
   a.dgrid_radius = c->dgrid_radius[0];
+  a.dgrid2 = c->dgrid[1];
+  a.dgrid2_radius = c->dgrid_radius[1];
   a.f32_delta = c->f32_delta;
   a.f32_range = c->f32_range;
   a.f32_delta_fk = c->f32_delta_fk;
@@ -539,20 +546,27 @@ bool fused_eligible(const mvk_ctx* c, uint64_t lanes) {
   return c->fused_enabled && c->flag_precision == MVK_PRECISION_F64 && lanes > 0 &&
          lanes <= static_cast<uint64_t>(kFusedMaxBlocks) * kBlock;
 }
+// sequence number of a call that reports through the pinned done word (16 bits: first_tag packs it)
+uint32_t next_seq(mvk_ctx* c) {
+  if (c->fused_seq >= 0xFFFFu) { c->fused_seq = 0u; c->tag_clear_needed = true; }
+  return ++c->fused_seq;
+}
 // after prepare_queue: the barrier / completion counters of this call's set, the next sequence number, the done word
 int fused_arm(mvk_ctx* c, EvalArgs& a, hipStream_t s, size_t n_edges) {
   a.fused = 1;
   a.fused_bar = a.queue_count + static_cast<size_t>(MVK_MAX_SEG * kQueueShards - 2) * kQueueCounterPitch;
   a.fused_done = a.queue_count + static_cast<size_t>(MVK_MAX_SEG * kQueueShards - 3) * kQueueCounterPitch;
-  c->fused_seq = c->fused_seq >= 0xFFFFu ? 1u : c->fused_seq + 1u;
-  a.fused_seq = c->fused_seq;
+  a.fused_seq = next_seq(c);
   a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
   if (n_edges) {
     const size_t before = c->first_tag.cap;
     if (int rc = c->first_tag.reserve(n_edges * sizeof(uint32_t))) return rc;
     // tags of an older call lose against this call's sequence number -- except after the 16-bit number has wrapped
     // (or in fresh memory): then the array is cleared once
-    if (c->fused_seq == 1u || c->first_tag.cap != before) HIP_TRY(hipMemsetAsync(c->first_tag.p, 0, c->first_tag.cap, s));
+    if (c->tag_clear_needed || c->first_tag.cap != before) {
+      HIP_TRY(hipMemsetAsync(c->first_tag.p, 0, c->first_tag.cap, s));
+      c->tag_clear_needed = false;
+    }
     a.first_tag = static_cast<uint32_t*>(c->first_tag.p);
   }
   return MVK_OK;
@@ -612,7 +626,7 @@ int prepare_queue(mvk_ctx* c, EvalArgs& a, uint64_t n) {
 
 int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
                  uint64_t* d_mask, double* d_min_dist, double* d_margin, uint8_t* d_band,
-                 const mvk_detail_out* det, bool force_full, hipStream_t s) {
+                 const mvk_detail_out* det, bool force_full, hipStream_t s, uint32_t poll_seq = 0) {
   if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
   if (n == 0) return MVK_OK;
@@ -641,9 +655,21 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
   c->stats_valid = false;
   if (a.full) {
     const uint64_t blocks = (n + kBlock - 1) / kBlock;
-    if (int rc = c->partial.reserve(blocks * sizeof(StatsPartial))) return rc;
+    // small batches with a collision stage: distance_small_kernel, a group of lanes per state (and a partial per
+    // block of kBlock / kSmallGroup states)
+    a.small_full = (a.do_coll && a.n_obs > 0 && !d_mask && n <= c->small_full_max && c->small_full_enabled) ? 1 : 0;
+    const uint64_t stat_blocks = a.small_full ? (n + (kBlock / kSmallGroup) - 1) / (kBlock / kSmallGroup) : blocks;
+    if (poll_seq) {  // eval_host: outputs in pinned memory, completion through the pinned done word
+      if (!a.small_full) return fail(MVK_ERR_INVALID_ARG, "internal: polled completion asked of a call that does not take distance_small_kernel");
+      a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
+      a.fused_seq = poll_seq;
+      a.fused_done = static_cast<uint32_t*>(c->small_done.p);
+      c->small_total += static_cast<uint32_t>(stat_blocks);
+      a.small_target = c->small_total;
+    }
+    if (int rc = c->partial.reserve(stat_blocks * sizeof(StatsPartial))) return rc;
     a.stats_partial = c->partial.p;
-    c->last_blocks = blocks;
+    c->last_blocks = stat_blocks;
     c->last_n = n;
     if (a.do_coll && a.n_obs > 0) {  // the distance kernel follows: hand-off rows for every launched lane
       const uint64_t rec_ld = blocks * kBlock;
@@ -767,11 +793,18 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
     return nullptr;
   }
   if ((e = hipMemset(c->queue_counts.p, 0, 2 * mvk_ctx::kQueueCounterSet * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(queue counters)", e);
+  if (c->small_done.reserve(256) != MVK_OK) {
+    mvk_destroy(c);
+    return nullptr;
+  }
+  if ((e = hipMemset(c->small_done.p, 0, 256)) != hipSuccess) return bail("hipMemset(small_done)", e);
   if (c->pin_ctl.reserve(4096) != MVK_OK) {
     mvk_destroy(c);
     return nullptr;
   }
   std::memset(c->pin_ctl.p, 0, 4096);
+  if (const char* off = std::getenv("MVK_NO_SMALL_FULL")) c->small_full_enabled = off[0] != '1';  // diagnostics, tests
+  if (const char* v = std::getenv("MVK_SMALL_FULL_MAX")) if (std::atoll(v) > 0) c->small_full_max = static_cast<uint64_t>(std::atoll(v));  // diagnostics
   if (const char* off = std::getenv("MVK_NO_FUSED")) c->fused_enabled = off[0] != '1';  // diagnostics: always two launches
   return c;
 }
@@ -791,7 +824,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
   if (c->d_extras) (void)hipFree(c->d_extras);
   Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start[0], &c->dgrid_items[0], &c->dgrid_start[1], &c->dgrid_items[1], &c->queue, &c->queue_rec, &c->queue_counts, &c->refine_list, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
-                &c->partial, &c->stats_out, &c->full_rec, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
+                &c->partial, &c->stats_out, &c->full_rec, &c->small_done, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
   for (Buf* b : all) b->release();
   c->edge_blob.release();
   c->first_tag.release();
@@ -1072,6 +1105,32 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
       return MVK_OK;
     }
     // (the grid barrier gave up: never seen; the two-launch path below repeats the call)
+  }
+  // Full path on a handful of states without detail rows (mvk_is_valid, clearance queries): the kernels read the rows
+  // from, and write the outputs to, pinned host memory, and the last block of distance_small_kernel raises the done
+  // word -- no copy, no stream synchronisation
+  if (!det && n <= 1024 && (force_full || min_dist || margin || band)) {
+    EvalArgs probe;
+    base_args(c, probe);
+    if (probe.do_coll && probe.n_obs > 0 && c->small_full_enabled) {
+      if (int rc = c->pin_up.reserve(dld * rows * sizeof(double))) return rc;
+      if (int rc = c->pin_down.reserve(2 * dld + 2 * dld * sizeof(double))) return rc;
+      double* up = static_cast<double*>(c->pin_up.p);
+      for (int r = 0; r < rows; ++r) std::memcpy(up + static_cast<size_t>(r) * dld, soa + static_cast<size_t>(r) * ld, n * sizeof(double));
+      unsigned char* down = static_cast<unsigned char*>(c->pin_down.p);
+      double* down_d = reinterpret_cast<double*>(down + 2 * dld);
+      const uint32_t seq = next_seq(c);
+      if (int rc = run_eval_dev(c, up, n, dld, layout, flags ? down : nullptr, nullptr, min_dist ? down_d : nullptr,
+                                margin ? down_d + dld : nullptr, band ? down + dld : nullptr, nullptr, force_full, s, seq))
+        return rc;
+      int gave_up = 0;
+      if (int rc = fused_wait(c, seq, s, &gave_up)) return rc;
+      if (flags) std::memcpy(flags, down, n);
+      if (band) std::memcpy(band, down + dld, n);
+      if (min_dist) std::memcpy(min_dist, down_d, n * sizeof(double));
+      if (margin) std::memcpy(margin, down_d + dld, n * sizeof(double));
+      return MVK_OK;
+    }
   }
   const bool staged = n <= (1u << 16);
   if (staged) {

@@ -178,6 +178,12 @@ struct EvalArgs {
   // kernel finishes the states itself): rows of full_rec_ld doubles -- cos/sin of every joint, then five scalars
   double* full_rec;
   uint64_t full_rec_ld;
+  // full path, small batches (distance_small_kernel): kSmallGroup lanes per state; the second, wider distance grid
+  // serves the primitives the first one cannot answer before the sweep over all boxes does
+  int32_t small_full;
+  uint32_t small_target;  // host_done set: the block that brings *fused_done to this count raises the done word
+  GridDev dgrid2;
+  double dgrid2_radius;
   // C-space sweep (mvk_sweep_mask_dev): states are generated from the sample index, nothing is read
   int32_t sweep_on;
   uint64_t sweep_first, sweep_seed;
@@ -207,6 +213,8 @@ struct StatsPartial {
 constexpr int kBlock = 256;
 constexpr int kQueueShards = 8;         // queues per segment (MVK_MAX_SEG * kQueueShards counters per set)
 constexpr int kQueueCounterPitch = 64;  // uint32 words between two counters: one 256-byte line each
+constexpr int kSmallGroup = 64;          // distance_small_kernel: lanes per state (>= MVK_MAX_PRIM)
+constexpr uint64_t kSmallFullMax = 4096;  // states per call up to which the full path takes distance_small_kernel (profiles/small_full_time.py)
 constexpr int kFusedMaxBlocks = 96;     // fused_kernel: every block resident at once (fewer than CUs); measured gain up to ~80 blocks (profiles/latency.py)
 
 

@@ -186,8 +186,10 @@ DEV double excess(double x, double h) {  // signed overshoot outside [-h, h]
 }
 DEV double excess_abs(double x, double h) { return fmax(fabs(x) - h, 0.0); }
 
-// tf::Matrix3x3::setRotation
+// tf::Matrix3x3::setRotation.  Products and sums as written (no fused multiply-add): which of the two products of
+// `xy - wz` the compiler fuses depends on the surrounding kernel, and every kernel must give a state the same matrix.
 DEV void quat_to_mat(double x, double y, double z, double w, double R[9]) {
+#pragma clang fp contract(off)
   const double d = x * x + y * y + z * z + w * w;
   double rd = __builtin_amdgcn_rcp(d);  // 1/d by Newton iteration (two steps: full precision) instead of a division
   rd = rd * fma(-d, rd, 2.0);
@@ -449,7 +451,10 @@ struct Shape {
   static constexpr int kScreenWaves = (!kGimbal && NL <= 4) ? 4 : 3;  // (NL = 8: see the LDS budget in screen_kernel)
 };
 
-constexpr int kListCap = 32;     // full path: per-lane narrowphase candidates per primitive
+#ifndef MVK_LIST_CAP
+#define MVK_LIST_CAP 32
+#endif
+constexpr int kListCap = MVK_LIST_CAP;     // full path: per-lane narrowphase candidates per primitive
 constexpr int kItemCap = 4 * kBlock;  // flag path: fp64 (state, box) pairs per block and primitive slot
 
 // LDS views.  The pointers carry the LDS address space explicitly so that every access is a
@@ -482,8 +487,14 @@ struct Smem {
   lds_uint* dring;
   lds_uint* dcnt;
 };
-constexpr int kUpperSlots = 16;
-constexpr int kExactBatch = 16;  // box pairs whose exact distance one wave computes together
+#ifndef MVK_UPPER_SLOTS
+#define MVK_UPPER_SLOTS 16
+#endif
+#ifndef MVK_EXACT_BATCH
+#define MVK_EXACT_BATCH 16
+#endif
+constexpr int kUpperSlots = MVK_UPPER_SLOTS;
+constexpr int kExactBatch = MVK_EXACT_BATCH;  // box pairs whose exact distance one wave computes together
 constexpr int kCpBatch = 8;      // the same for the avoidance rows (closest points as well)
 constexpr int kExactItem = 16;   // doubles per pair: relative rotation 9, centre 3, box half extents 3, pad
 
@@ -1235,6 +1246,13 @@ DEV double box_box_exact(const double t[3], const double Rr[9], const double a[3
   return sqrt(s2);
 }
 
+// The separating-axis gap bounds a pair's distance from below only up to rounding: for two pairs at the same
+// distance (the flat bodies of a planar robot under one box face) the gap of the second can come out an ulp above the
+// exact distance of the first, and whether the second is then evaluated would depend on the order of the pairs.  A
+// pair is therefore skipped only when its gap exceeds the running minimum by kSatSlack, which makes the minimum
+// independent of the order (distance_kernel and distance_small_kernel visit the pairs in different orders).
+constexpr double kSatSlack = 1e-9;
+
 // exact test of one primitive against one box (primitive kind is wave-uniform); t = primitive
 // centre in the box frame.  SIGNED: signed distance; otherwise only the sign is meaningful.
 // `cutoff` (SIGNED only): the caller keeps a running minimum; when the separating-axis bound of a box
@@ -1260,8 +1278,8 @@ DEV double narrow(int type, const double PR[9], double d0, double d1, double d2,
     box_rel(O, PR, Rr);
     const double a[3] = {d0, d1, d2};
     if (SIGNED) {
-      d = box_box_sat<true>(t, Rr, a, O.h, cutoff);
-      if (d > 0.0 && d < cutoff) d = box_box_exact(t, Rr, a, O.h);
+      d = box_box_sat<true>(t, Rr, a, O.h, cutoff + kSatSlack);
+      if (d > 0.0 && d < cutoff + kSatSlack) d = box_box_exact(t, Rr, a, O.h);
     } else {
       d = box_box_sat<false>(t, Rr, a, O.h);
     }
@@ -2052,7 +2070,11 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       bool swept = false;
       unsigned cell_b = 0, cell_e = 0;  // the grid cell's groups, when the candidates came from it
       if (use_grid) {
+#ifdef MVK_EXP_DECOUPLE
+        const double bound = upper;
+#else
         const double bound = fmin(mind, upper);
+#endif
         // the first walk's minimum for this primitive: when even its nearest box (of a list that is complete for the
         // threshold) is too far to undercut the bound -- lower bound: centre distance - bounding radius -- there is
         // nothing to collect: most primitives of a state, since only the few nearest matter
@@ -2075,7 +2097,11 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
             const double est = static_cast<double>(sqrtf(__uint_as_float(*up_slot)));
             up_q = est * 0.999999;
             upper = fmin(upper, est * 1.000001 + delta);
+#ifdef MVK_EXP_DECOUPLE
+            thr0 = rb + fmax(upper, 0.0);
+#else
             thr0 = rb + fmax(fmin(mind, upper), 0.0);
+#endif
           }
         }
         const bool none = (qi < kUpperSlots || far) && on && up_q - delta > thr0 + dd;
@@ -2163,9 +2189,9 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
               to_box_frame(O, pc, t);
               box_rel(O, PR, Rr);
               h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
-              const double g = box_box_sat<true>(t, Rr, a, h, mind);
+              const double g = box_box_sat<true>(t, Rr, a, h, mind + kSatSlack);
               if (g <= 0.0) mind = fmin(mind, g);
-              else need = g < mind;
+              else need = g < mind + kSatSlack;
             }
             ++e;
           }
@@ -3272,6 +3298,219 @@ distance_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
               mind, margin >= 0.0);
 }
 
+// Exact distances of the box pairs some lanes of a wave hold (`need`), computed by the whole wave as in collide_full:
+// kExactBatch pairs at a time go to LDS with their two half-extent triples (the primitive differs from lane to lane
+// here), every lane takes (pair, edge) items, an LDS atomic min merges each pair's 24 squared edge distances.  Returns
+// the pair's distance to its lane (+inf to the others): the same bits as box_box_exact.
+constexpr int kExactItemAB = 18;  // relative rotation 9, centre 3, box half extents 3, primitive half extents 3
+DEV double exact_wave_ab(lds_double* item, lds_u64* res, bool need, const double Rr[9], const double t[3], const double h[3],
+                         const double a[3]) {
+  const int lane = threadIdx.x & 63;
+  double out = INFINITY;
+  unsigned long long pend = __ballot(need);
+#pragma unroll 1
+  while (pend) {
+    const int rank = __popcll(pend & ((1ull << lane) - 1ull));
+    const bool mine = need && ((pend >> lane) & 1ull) && rank < kExactBatch;
+    const int E = min(static_cast<int>(__popcll(pend)), kExactBatch);
+    if (mine) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) item[rank * kExactItemAB + c] = Rr[c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        item[rank * kExactItemAB + 9 + c] = t[c];
+        item[rank * kExactItemAB + 12 + c] = h[c];
+        item[rank * kExactItemAB + 15 + c] = a[c];
+      }
+      res[rank] = 0x7FF0000000000000ull;  // +inf
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int it = lane; it < 24 * E; it += 64) {
+      const int pr = it / 24, ed = it - 24 * pr;
+      double iR[9], it_[3], ih[3], ia[3];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) iR[c] = item[pr * kExactItemAB + c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        it_[c] = item[pr * kExactItemAB + 9 + c];
+        ih[c] = item[pr * kExactItemAB + 12 + c];
+        ia[c] = item[pr * kExactItemAB + 15 + c];
+      }
+      const bool second = ed >= 12;  // edges 0..11: the primitive's against the box; 12..23: the box's against the primitive
+      double cR[9], cc[3], ca[3], cb[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cR[3 * r + c] = second ? iR[3 * c + r] : iR[3 * r + c];
+        const double tb = -fma(iR[r], it_[0], fma(iR[3 + r], it_[1], iR[6 + r] * it_[2]));
+        cc[r] = second ? tb : it_[r];
+        ca[r] = second ? ih[r] : ia[r];
+        cb[r] = second ? ia[r] : ih[r];
+      }
+      const double s2 = box_edge_to_box2(second ? ed - 12 : ed, cc, cR, ca, cb);
+      __hip_atomic_fetch_min(&res[pr], static_cast<unsigned long long>(__double_as_longlong(s2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (mine) out = sqrt(__longlong_as_double(static_cast<long long>(res[rank])));
+    pend &= ~__ballot(mine);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return out;
+}
+
+// The same stage for small batches (mvk_is_valid, the states of a densified path): distance_kernel gives a state one
+// lane, which then walks its primitives and their candidate lists one after the other -- 0.16 ms for a single state,
+// whatever the size of the batch up to a chip-full.  Here a state has a wave of its own (kSmallGroup lanes): lane (qi, part) takes
+// primitive qi of the chain order and every K-th box of its candidate list, K = kSmallGroup / P slices per primitive.
+// Everything is fp64: per lane the centre distance against the bound and the separating-axis gap; the exact edge
+// distances of the box pairs whose gap undercuts the minimum are computed by the whole wave (exact_wave_ab: one lane
+// alone would take ~20 us per pair); the running minimum is shared by the group after every round.
+// The result is the minimum of the same per-pair values as in distance_kernel (a pair is skipped only when its lower
+// bound, centre distance - bounding radius, cannot undercut max(minimum, 0)), so it carries the same bits.
+// Candidates: the distance grid's cell list of the primitive's centre (complete within dgrid_radius); a primitive the
+// list cannot answer (rb + max(minimum, 0) beyond the radius) goes on to the wider second grid, then to all boxes.
+static_assert(kSmallGroup >= MVK_MAX_PRIM && kBlock % kSmallGroup == 0 && kSmallGroup <= 64 && 64 % kSmallGroup == 0, "one group per state inside a wave");
+template <int ROBOT, int NL>
+__global__ void __launch_bounds__(kBlock)
+distance_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                      const DevObs* __restrict__ obs) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ double sm_ex_item[(kBlock / 64) * kExactBatch * kExactItemAB];
+  __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kExactBatch];
+  const int tid = threadIdx.x, sub = tid & (kSmallGroup - 1);
+  lds_double* ex_item = (lds_double*)sm_ex_item + (tid >> 6) * kExactBatch * kExactItemAB;
+  lds_u64* ex_res = (lds_u64*)sm_ex_res + (tid >> 6) * kExactBatch;
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * (kBlock / kSmallGroup) + static_cast<uint64_t>(tid / kSmallGroup);
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, false, false>(A, li, st, edge, step);
+  // the joints' cos/sin rows of the model kernel, all loads in flight at once
+  double cs[2 * NJ];
+#pragma unroll
+  for (int r = 0; r < 2 * NJ; ++r) cs[r] = A.full_rec[static_cast<uint64_t>(r) * A.full_rec_ld + li];
+  double R[9], p[3] = {st[0], st[1], st[2]};
+  quat_to_mat(st[3], st[4], st[5], st[6], R);
+  const double* __restrict__ sc = A.full_rec + static_cast<uint64_t>(2 * NJ) * A.full_rec_ld;
+  const bool finite = sc[static_cast<uint64_t>(kFullRecFinite) * A.full_rec_ld + li] != 0.0;
+
+  const int P = M->n_prim;
+  const int K = kSmallGroup / P;  // >= 1 (P <= MVK_MAX_PRIM)
+  const bool active = in_range && finite && sub < P * K;
+  const int qi = sub % P, part = sub / P;
+  const int q = X->prim_order[qi];
+  int myk = 0;
+#pragma unroll 1
+  for (int k = 1; k < S::kSeg; ++k) myk = qi >= X->seg_prim_begin[k] ? k : myk;
+  // the chain up to this lane's segment: advance_frame with the joint index and axis known at compile time
+  static_for<1, S::kSeg>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if (k <= myk) {
+      double pn[3];
+      xform(R, p, M->seg_t[k][0], M->seg_t[k][1], M->seg_t[k][2], pn);
+      p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+      rot_cols<S::axis(k)>(R, cs[2 * S::joint(k)], cs[2 * S::joint(k) + 1]);
+    }
+  });
+  double pc[3], PR[9];
+  prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
+  const int type = M->prim_type[q];
+  const bool sphere = type == MVK_PRIM_SPHERE;
+  const double rb = X->prim_bound[q];
+  const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+
+  double best = INFINITY;  // the group's running minimum (after group_min: the same in all its lanes)
+  auto group_min = [&](double v) {
+#pragma unroll
+    for (int off = kSmallGroup / 2; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+  };
+  // two boxes per round, their loads independent: centre distances first, the narrowphase for those within reach
+  auto centre = [&](int ob, double t[3]) -> double {
+    if (ob == kGridNone) return INFINITY;
+    to_box_frame(obs[ob], pc, t);
+    return point_box_dist2(t, obs[ob].h);
+  };
+  // (called by the whole wave: the exact stage is shared)
+  const double a[3] = {d0, d1, d2};
+  auto finish = [&](int ob, const double t[3], double l2) {
+    const double thr = rb + fmax(best, 0.0);
+    const bool reach = ob != kGridNone && l2 <= thr * thr * (1.0 + 1e-12);
+    bool need = false;
+    double Rr[9], h[3];
+    if (reach) {
+      if (type == MVK_PRIM_BOX) {  // as narrow<true>, with the exact distance left to the wave
+        const DevObs& O = obs[ob];
+        box_rel(O, PR, Rr);
+        h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
+        const double g = box_box_sat<true>(t, Rr, a, h, best + kSatSlack);
+        if (g <= 0.0) best = fmin(best, g);
+        else need = g < best + kSatSlack;
+      } else {
+        best = fmin(best, sphere ? sqrt(l2) - d0 : narrow<true>(type, PR, d0, d1, d2, obs[ob], t, best));
+      }
+    }
+    best = fmin(best, exact_wave_ab(ex_item, ex_res, need, Rr, t, h, a));
+  };
+  auto scan = [&](const uint16_t* __restrict__ ids, int n_items) {  // ids == nullptr: boxes 0 .. n_items-1
+#pragma unroll 1
+    for (int e = part; __any(e < n_items); e += 2 * K) {
+      const int e1 = e + K;
+      const int ob0 = e < n_items ? (ids ? ids[e] : e) : kGridNone;
+      const int ob1 = e1 < n_items ? (ids ? ids[e1] : e1) : kGridNone;
+      double t0[3], t1[3];
+      const double l0 = centre(ob0, t0), l1 = centre(ob1, t1);
+      finish(ob0, t0, l0);
+      finish(ob1, t1, l1);
+      best = group_min(best);
+    }
+  };
+  auto scan_cell = [&](const GridDev& G, bool who) {
+    unsigned gb, ge;
+    grid_cell(G, pc, who, gb, ge);
+    scan(G.items + static_cast<size_t>(gb) * kGridGroup, static_cast<int>(ge - gb) * kGridGroup);
+  };
+  const double pad = 1e-9;
+  bool todo = active;  // primitives whose candidates are not complete yet
+  if (A.dgrid.start != nullptr) {
+    scan_cell(A.dgrid, todo);
+    todo = todo && !(rb + fmax(best, 0.0) + pad <= A.dgrid_radius);
+    if (A.dgrid2.start != nullptr && A.dgrid2_radius > A.dgrid_radius && __any(todo)) {
+      scan_cell(A.dgrid2, todo);
+      todo = todo && !(rb + fmax(best, 0.0) + pad <= A.dgrid2_radius);
+    }
+  }
+  if (__any(todo)) scan(nullptr, todo ? A.n_obs : 0);
+  const double mind = group_min(best);
+
+  const bool report = in_range && sub == 0;
+  const double margin = sc[static_cast<uint64_t>(kFullRecMargin) * A.full_rec_ld + li];
+  full_finish(A, gi, report, finite, margin, sc[static_cast<uint64_t>(kFullRecLamMin) * A.full_rec_ld + li],
+              sc[static_cast<uint64_t>(kFullRecLamMax) * A.full_rec_ld + li], sc[static_cast<uint64_t>(kFullRecRp) * A.full_rec_ld + li],
+              mind, margin >= 0.0);
+  // a host caller polling a pinned word instead of synchronising the stream (outputs in pinned memory): every block
+  // releases its writes to the system, the last one to arrive raises the word
+  if (A.host_done) {
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence_system();
+      const unsigned before = atomicAdd(A.fused_done, 1u);
+      if (before + 1u == A.small_target) {
+        __threadfence_system();
+        *A.host_done = A.fused_seq;
+      }
+    }
+  }
+}
+
 
 // Collision-avoidance constraint rows: differential_kinematics CollisionAvoidance::getConstraint
 // (src/constraint/collision_avoidance.cpp:102-277) for a batch of states.  One lane per state;
@@ -3683,7 +3922,12 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s, hipEvent_t* e
   if (a.full && !edge_mode) {
     hipLaunchKernelGGL((model_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras);
     if (ev) (void)hipEventRecord(ev[1], s);
-    if (a.full_rec) hipLaunchKernelGGL((distance_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras, a.obs);
+    if (a.full_rec && a.small_full) {
+      const dim3 gs(static_cast<unsigned>((a.n + (kBlock / kSmallGroup) - 1) / (kBlock / kSmallGroup)));
+      hipLaunchKernelGGL((distance_small_kernel<ROBOT, NL>), gs, b, 0, s, a, a.model, a.extras, a.obs);
+    } else if (a.full_rec) {
+      hipLaunchKernelGGL((distance_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras, a.obs);
+    }
     if (ev) (void)hipEventRecord(ev[2], s);
     return hipGetLastError();
   }

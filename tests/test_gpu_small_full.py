@@ -1,0 +1,113 @@
+"""Full path (verdict + exact minimum distance + margin + band + statistics) on small batches: up to 4096 states per
+call go through distance_small_kernel (a group of 32 lanes per state, one lane per primitive and list slice) instead
+of distance_kernel (one lane per state); MVK_NO_SMALL_FULL=1 keeps the latter.  Both take the minimum of the same
+per-pair values, so every output must carry the same bits, and both must agree with the oracle.
+
+Reference: the per-state call MotionPlanning::isStateValid (motion_planning.cpp:76-164) and the statistics of addState
+(:546-642) that mvk_is_valid / mvk_eval_batch / mvk_reduce_stats stand for."""
+import numpy as np
+import pytest
+
+import common
+import motion_planning_amd as mp
+import oracle_lib as O
+from motion_planning_amd import _abi as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _workloads():
+    w = common.config2k(n=4096)
+    yield "c2k", w.model, w.boxes, w.params, w.soa, w.layout
+    w = common.config3(n=4096)
+    yield "c3 dragon", w.model, w.boxes, w.params, w.soa, w.layout
+    w = common.config2(n=4096)
+    yield "c2 (100 boxes)", w.model, w.boxes, w.params, w.soa, w.layout
+    w = common.config5(n=4096)
+    yield "c5 hydrus-8", w.model, w.boxes, w.params, w.soa, w.layout
+    # far from every box: neither distance grid can answer, the sweep over all boxes does
+    w = common.config2k(n=2048)
+    far = w.soa.copy()
+    far[0] += 9.0
+    far[2] += np.linspace(0.0, 6.0, far.shape[1])
+    yield "c2k far away", w.model, w.boxes, w.params, far, w.layout
+    # fewer than 64 boxes: no distance grid at all
+    model, params, boxes, start, goal = common.config1()
+    rng = np.random.default_rng(4)
+    st = common.hydrus_states(rng, 1024, model.n_joint)
+    st[0] = rng.uniform(-1.5, 1.5, 1024)
+    st[1] = rng.uniform(-1.5, 1.5, 1024)
+    st[2] = 0.0
+    yield "c1 gap world", model, boxes, params, st, A.LAYOUT_POSE7
+
+
+def _same(a, b, key):
+    x, y = a[key], b[key]
+    return np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("name,model,boxes,params,soa,layout", list(_workloads()), ids=lambda v: v if isinstance(v, str) else "")
+def test_group_per_state_kernel_equals_lane_per_state_kernel(monkeypatch, name, model, boxes, params, soa, layout):
+    soa = soa.copy()
+    soa[7, 5] = np.nan          # a non-finite state: invalid, band, NaN distance, out of the statistics
+    soa[0, 11] = np.inf
+    sizes = (1, 3, 4, 5, 33, 300, min(4096, soa.shape[1]))
+    out, stats = {}, {}
+    for small in (True, False):
+        if not small:
+            monkeypatch.setenv("MVK_NO_SMALL_FULL", "1")
+        eng = mp.Engine(model, boxes, params)
+        out[small] = [eng.eval_batch(soa[:, :n], layout) for n in sizes]
+        stats[small] = eng.reduce_stats()          # of the last call
+        eng.close()
+    for a, b, n in zip(out[True], out[False], sizes):
+        for key in ("flags", "band", "min_dist", "margin", "fc_t_min", "thrust", "cog"):
+            assert _same(a, b, key), (name, n, key, np.flatnonzero(a[key] != b[key])[:5])
+    assert stats[True] == stats[False], (stats[True], stats[False])
+    # and against the oracle (the tolerances of test_gpu_parity.py)
+    n = sizes[-1]
+    ref = O.eval_batch(model, boxes, params, soa[:, :n], layout, threads=8)
+    got = out[True][-1]
+    clear = ~ref["band"].astype(bool)
+    assert np.array_equal(got["flags"][clear], ref["flags"][clear])
+    fin = np.isfinite(ref["min_dist"])
+    assert np.array_equal(np.isfinite(got["min_dist"]), fin)
+    assert np.allclose(got["min_dist"][fin], ref["min_dist"][fin], rtol=0, atol=1e-9)
+    assert not got["flags"][5] and got["band"][5] and np.isnan(got["min_dist"][5])
+
+
+def test_single_state_call_matches_the_oracle():
+    """mvk_is_valid (one state in the OMPL layout of mode 2 / SE2: x, y, yaw, joints; z = 0)"""
+    w = common.config2k(n=64)
+    soa = w.soa.copy()
+    soa[2] = 0.0
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    ref = O.eval_batch(w.model, w.boxes, w.params, soa, w.layout)
+    for i in range(64):
+        s = soa[:, i]
+        yaw = 2.0 * np.arctan2(s[5], s[6])
+        r = eng.is_valid(np.concatenate([s[0:2], [yaw], s[7:]]))
+        assert abs(r.min_dist - ref["min_dist"][i]) < 1e-9 and abs(r.margin - ref["margin"][i]) < 1e-5 * max(1.0, abs(ref["margin"][i])), i
+        if not ref["band"][i]:
+            assert r.valid == ref["flags"][i] and r.collision == (ref["min_dist"][i] <= 0.0), i
+    eng.close()
+
+
+def test_many_small_full_calls_in_a_row_keep_their_answers_apart():
+    """host calls of up to 1024 states read and write pinned memory and are reported done through a pinned word by the
+    last block of the kernel: a few hundred calls of changing size on one context, interleaved with flag-only calls
+    (which share the word and its sequence numbers), against one large call (lane-per-state kernel) on the same states"""
+    w = common.config2k(n=8192)
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    big = eng.is_valid_batch(w.soa, w.layout, want=("flags", "min_dist", "margin", "band"))
+    rng = np.random.default_rng(3)
+    for it in range(400):
+        n = int(rng.integers(1, 1025 if it % 50 == 0 else 41))
+        a = int(rng.integers(0, 8192 - n))
+        got = eng.is_valid_batch(w.soa[:, a:a + n], w.layout, want=("flags", "min_dist", "margin", "band"))
+        for key in ("flags", "min_dist", "margin", "band"):
+            assert np.array_equal(got[key], big[key][a:a + n]), (it, n, a, key)
+        if it % 3 == 0:
+            f = eng.is_valid_batch(w.soa[:, a:a + n], w.layout)["flags"]
+            assert np.array_equal(f, big["flags"][a:a + n]), (it, n, a)
+    eng.close()
