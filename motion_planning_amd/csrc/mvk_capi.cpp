@@ -122,6 +122,7 @@ struct mvk_ctx {
   Buf small_done;                  // distance_small_kernel: blocks finished, over all polled calls (never reset)
   uint32_t small_total = 0;        // ... and the count the last polled call ends on
   bool tag_clear_needed = false;   // the call sequence number has wrapped since first_tag was last cleared
+  uint64_t small_avoid_max = kSmallAvoidMax;  // the same for the avoidance rows (avoid_small_kernel)
   uint64_t small_full_max = kSmallFullMax;  // states per call up to which the full path takes distance_small_kernel
   bool small_full_enabled = true;  // full path: distance_small_kernel for small batches (MVK_NO_SMALL_FULL=1: never)
   bool fused_in_flight = false;   // (edge checks begun with _begin)
@@ -804,7 +805,7 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
   }
   std::memset(c->pin_ctl.p, 0, 4096);
   if (const char* off = std::getenv("MVK_NO_SMALL_FULL")) c->small_full_enabled = off[0] != '1';  // diagnostics, tests
-  if (const char* v = std::getenv("MVK_SMALL_FULL_MAX")) if (std::atoll(v) > 0) c->small_full_max = static_cast<uint64_t>(std::atoll(v));  // diagnostics
+  if (const char* v = std::getenv("MVK_SMALL_FULL_MAX")) if (std::atoll(v) > 0) c->small_full_max = c->small_avoid_max = static_cast<uint64_t>(std::atoll(v));  // diagnostics
   if (const char* off = std::getenv("MVK_NO_FUSED")) c->fused_enabled = off[0] != '1';  // diagnostics: always two launches
   return c;
 }
@@ -1269,8 +1270,9 @@ extern "C" int mvk_avoid_params_default(mvk_avoid_params* p) {
   return MVK_OK;
 }
 
-extern "C" int mvk_collision_avoidance_batch_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout,
-                                                 const mvk_avoid_params* prm, const mvk_avoid_out* o, void* stream) {
+namespace {
+int run_avoid_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout, const mvk_avoid_params* prm,
+                  const mvk_avoid_out* o, void* stream, uint32_t poll_seq) {
   if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c || !prm || !o) return fail(MVK_ERR_INVALID_ARG, "null argument");
   if (n == 0) return MVK_OK;
@@ -1293,11 +1295,27 @@ extern "C" int mvk_collision_avoidance_batch_dev(mvk_ctx* c, const double* d_soa
   a.av_full_body = prm->full_body;
   a.av_dist = o->dist; a.av_box = o->box; a.av_p_env = o->p_env; a.av_p_robot = o->p_robot;
   a.av_row = o->row; a.av_lb = o->lb; a.av_ok = o->ok;
+  // small batches (the one state of a QP iteration): avoid_small_kernel, a wave per state
+  a.small_full = (n <= c->small_avoid_max && c->small_full_enabled) ? 1 : 0;
+  if (poll_seq) {  // host entry: outputs in pinned memory, completion through the pinned done word
+    if (!a.small_full) return fail(MVK_ERR_INVALID_ARG, "internal: polled completion asked of a call that does not take avoid_small_kernel");
+    a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
+    a.fused_seq = poll_seq;
+    a.fused_done = static_cast<uint32_t*>(c->small_done.p);
+    c->small_total += static_cast<uint32_t>((n + (kBlock / 64) - 1) / (kBlock / 64));
+    a.small_target = c->small_total;
+  }
   c->stats_valid = false;
   if (int rc = enter_stream(c, static_cast<hipStream_t>(stream))) return rc;
   const int e = launch_avoid(a, c->model.robot_type, c->model.n_rotor, stream);
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "avoidance kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
   return leave_stream(c, static_cast<hipStream_t>(stream));
+}
+}  // namespace
+
+extern "C" int mvk_collision_avoidance_batch_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout,
+                                                 const mvk_avoid_params* prm, const mvk_avoid_out* o, void* stream) {
+  return run_avoid_dev(c, d_soa, n, ld, layout, prm, o, stream, 0);
 }
 
 extern "C" int mvk_collision_avoidance_batch(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout,
@@ -1313,11 +1331,47 @@ extern "C" int mvk_collision_avoidance_batch(mvk_ctx* c, const double* soa, size
   hipStream_t s = c->stream;
   if (int rc = enter_stream(c, s)) return rc;  // the staging buffers may still feed a call on a caller's stream
   const size_t dld = round_up(n, 64), P = static_cast<size_t>(c->model.n_prim), W = 6 + static_cast<size_t>(c->model.n_joint);
-  if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
-  if (int rc = copy_rows(c->in_a.p, dld, soa, ld, sizeof(double), n, rows, hipMemcpyHostToDevice, s)) return rc;
   void* host[7] = {o->dist, o->box, o->p_env, o->p_robot, o->row, o->lb, o->ok};
   const size_t nrows[7] = {P, P, 3 * P, 3 * P, W * P, P, 1};
   const size_t elem[7] = {8, 4, 8, 8, 8, 8, 1};
+  // A few states (the one state of a QP iteration): the kernel reads the rows from, and writes every output to,
+  // pinned host memory and its last block raises the done word -- no copy, no stream synchronisation
+  if (n <= 256 && n <= c->small_avoid_max && c->small_full_enabled) {
+    if (int rc = c->pin_up.reserve(dld * rows * sizeof(double))) return rc;
+    double* up = static_cast<double*>(c->pin_up.p);
+    for (int r = 0; r < rows; ++r) std::memcpy(up + static_cast<size_t>(r) * dld, soa + static_cast<size_t>(r) * ld, n * sizeof(double));
+    size_t off[7], total = 0;
+    for (int k = 0; k < 7; ++k) {
+      off[k] = total;
+      if (host[k]) total += round_up(dld * nrows[k] * elem[k], 256);
+    }
+    if (int rc = c->pin_down.reserve(total ? total : 256)) return rc;
+    unsigned char* down = static_cast<unsigned char*>(c->pin_down.p);
+    void* pd[7];
+    for (int k = 0; k < 7; ++k) pd[k] = host[k] ? down + off[k] : nullptr;
+    mvk_avoid_out d{static_cast<double*>(pd[0]), static_cast<int32_t*>(pd[1]), static_cast<double*>(pd[2]), static_cast<double*>(pd[3]),
+                    static_cast<double*>(pd[4]), static_cast<double*>(pd[5]), static_cast<uint8_t*>(pd[6])};
+    const uint32_t seq = next_seq(c);
+    if (int rc = run_avoid_dev(c, up, n, dld, layout, prm, &d, s, seq)) return rc;
+    int gave_up = 0;
+    if (int rc = fused_wait(c, seq, s, &gave_up)) return rc;
+    for (int k = 0; k < 7; ++k)
+      if (host[k])
+        for (size_t r = 0; r < nrows[k]; ++r)
+          std::memcpy(static_cast<unsigned char*>(host[k]) + r * ld * elem[k], static_cast<unsigned char*>(pd[k]) + r * dld * elem[k], n * elem[k]);
+    return MVK_OK;
+  }
+  if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
+  // up to 8192 states: rows and outputs staged through pinned blocks, one contiguous copy each (as eval_host)
+  const bool staged = n <= 8192;
+  if (staged) {
+    if (int rc = c->pin_up.reserve(dld * rows * sizeof(double))) return rc;
+    double* up = static_cast<double*>(c->pin_up.p);
+    for (int r = 0; r < rows; ++r) std::memcpy(up + static_cast<size_t>(r) * dld, soa + static_cast<size_t>(r) * ld, n * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(c->in_a.p, up, dld * rows * sizeof(double), hipMemcpyHostToDevice, s));
+  } else if (int rc = copy_rows(c->in_a.p, dld, soa, ld, sizeof(double), n, rows, hipMemcpyHostToDevice, s)) {
+    return rc;
+  }
   void* dev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int k = 0; k < 7; ++k)
     if (host[k]) {
@@ -1328,6 +1382,23 @@ extern "C" int mvk_collision_avoidance_batch(mvk_ctx* c, const double* soa, size
                   static_cast<double*>(dev[3]), static_cast<double*>(dev[4]), static_cast<double*>(dev[5]),
                   static_cast<uint8_t*>(dev[6])};
   if (int rc = mvk_collision_avoidance_batch_dev(c, static_cast<const double*>(c->in_a.p), n, dld, layout, prm, &d, s)) return rc;
+  if (staged) {
+    size_t off[7], total = 0;
+    for (int k = 0; k < 7; ++k) {
+      off[k] = total;
+      if (host[k]) total += round_up(dld * nrows[k] * elem[k], 256);
+    }
+    if (int rc = c->pin_down.reserve(total ? total : 256)) return rc;
+    unsigned char* down = static_cast<unsigned char*>(c->pin_down.p);
+    for (int k = 0; k < 7; ++k)
+      if (host[k]) HIP_TRY(hipMemcpyAsync(down + off[k], dev[k], dld * nrows[k] * elem[k], hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < 7; ++k)
+      if (host[k])
+        for (size_t r = 0; r < nrows[k]; ++r)
+          std::memcpy(static_cast<unsigned char*>(host[k]) + r * ld * elem[k], down + off[k] + r * dld * elem[k], n * elem[k]);
+    return MVK_OK;
+  }
   for (int k = 0; k < 7; ++k)
     if (host[k])
       if (int rc = copy_rows(host[k], ld, dev[k], dld, elem[k], n, nrows[k], hipMemcpyDeviceToHost, s)) return rc;

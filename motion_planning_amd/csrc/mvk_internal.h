@@ -215,6 +215,7 @@ constexpr int kQueueShards = 8;         // queues per segment (MVK_MAX_SEG * kQu
 constexpr int kQueueCounterPitch = 64;  // uint32 words between two counters: one 256-byte line each
 constexpr int kSmallGroup = 64;          // distance_small_kernel: lanes per state (>= MVK_MAX_PRIM)
 constexpr uint64_t kSmallFullMax = 4096;  // states per call up to which the full path takes distance_small_kernel (profiles/small_full_time.py)
+constexpr uint64_t kSmallAvoidMax = 4096; // ... and the avoidance rows avoid_small_kernel
 constexpr int kFusedMaxBlocks = 96;     // fused_kernel: every block resident at once (fewer than CUs); measured gain up to ~80 blocks (profiles/latency.py)
 
 

@@ -3362,6 +3362,98 @@ DEV double exact_wave_ab(lds_double* item, lds_u64* res, bool need, const double
   return out;
 }
 
+// The same with the closest points (avoidance rows): an LDS atomic min per pair over its 24 squared distances, a second
+// one over the edge indices that reach it (the lowest wins, as in the one-lane form box_box_exact_cp: robot edges
+// before box edges, ascending), and the owner lane repeats that one edge for its points.  Same arithmetic per edge,
+// so the result keeps its bits.  pr on the primitive, pq on the box, both in the box frame.
+DEV double exact_cp_wave_ab(lds_double* item, lds_u64* res, lds_double* s2s, lds_uint* win, bool need, const double Rr[9],
+                            const double t[3], const double h[3], const double a[3], double pr[3], double pq[3]) {
+  const int lane = threadIdx.x & 63;
+  double out = INFINITY;
+  // one (pair, edge): inputs as box_box_exact_cp builds them for its two halves
+  auto edge_item = [&](const double iR[9], const double it_[3], const double ih[3], const double ia[3], int ed, double y[3], double z[3]) {
+    const bool second = ed >= 12;
+    double cR[9], cc[3], ca[3], cb[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) cR[3 * r + c] = second ? iR[3 * c + r] : iR[3 * r + c];
+      const double tb = -fma(iR[r], it_[0], fma(iR[3 + r], it_[1], iR[6 + r] * it_[2]));
+      cc[r] = second ? tb : it_[r];
+      ca[r] = second ? ih[r] : ia[r];
+      cb[r] = second ? ia[r] : ih[r];
+    }
+    return box_edge_to_box_cp2(second ? ed - 12 : ed, cc, cR, ca, cb, y, z);
+  };
+  unsigned long long pend = __ballot(need);
+#pragma unroll 1
+  while (pend) {
+    const int rank = __popcll(pend & ((1ull << lane) - 1ull));
+    const bool mine = need && ((pend >> lane) & 1ull) && rank < kCpBatch;
+    const int E = min(static_cast<int>(__popcll(pend)), kCpBatch);
+    if (mine) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) item[rank * kExactItemAB + c] = Rr[c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        item[rank * kExactItemAB + 9 + c] = t[c];
+        item[rank * kExactItemAB + 12 + c] = h[c];
+        item[rank * kExactItemAB + 15 + c] = a[c];
+      }
+      res[rank] = 0x7FF0000000000000ull;  // +inf
+      win[rank] = 0xFFFFFFFFu;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int it = lane; it < 24 * E; it += 64) {
+      const int pr_ = it / 24, ed = it - 24 * pr_;
+      double iR[9], it_[3], ih[3], ia[3], y[3], z[3];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) iR[c] = item[pr_ * kExactItemAB + c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        it_[c] = item[pr_ * kExactItemAB + 9 + c];
+        ih[c] = item[pr_ * kExactItemAB + 12 + c];
+        ia[c] = item[pr_ * kExactItemAB + 15 + c];
+      }
+      const double s2 = edge_item(iR, it_, ih, ia, ed, y, z);
+      s2s[it] = s2;
+      __hip_atomic_fetch_min(&res[pr_], static_cast<unsigned long long>(__double_as_longlong(s2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int it = lane; it < 24 * E; it += 64) {
+      const int pr_ = it / 24, ed = it - 24 * pr_;
+      if (static_cast<unsigned long long>(__double_as_longlong(s2s[it])) == res[pr_])
+        __hip_atomic_fetch_min(&win[pr_], static_cast<unsigned>(ed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (mine) {
+      const int ed = static_cast<int>(win[rank]);
+      double y[3], z[3];
+      const double s2 = edge_item(Rr, t, h, a, ed, y, z);
+      if (ed < 12) {  // y on the robot's edge, z on the box (box frame)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pr[c] = y[c]; pq[c] = z[c]; }
+      } else {        // y on the box's edge, z on the robot (primitive frame): x_B = Rr x_A + t
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          pq[c] = fma(Rr[3 * c], y[0], fma(Rr[3 * c + 1], y[1], fma(Rr[3 * c + 2], y[2], t[c])));
+          pr[c] = fma(Rr[3 * c], z[0], fma(Rr[3 * c + 1], z[1], fma(Rr[3 * c + 2], z[2], t[c])));
+        }
+      }
+      out = sqrt(s2);
+    }
+    pend &= ~__ballot(mine);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return out;
+}
+
 // The same stage for small batches (mvk_is_valid, the states of a densified path): distance_kernel gives a state one
 // lane, which then walks its primitives and their candidate lists one after the other -- 0.16 ms for a single state,
 // whatever the size of the batch up to a chip-full.  Here a state has a wave of its own (kSmallGroup lanes): lane (qi, part) takes
@@ -3659,7 +3751,7 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
         PROF_CLK(3, t_a);
         PROF_T0(t_f);
         {
-          const bool first = emin >= 0 && gmin <= best;
+          const bool first = emin >= 0 && gmin <= best + kSatSlack;
           if (__any(first)) {
             if (first) {
               const int ob = cand(emin);
@@ -3686,8 +3778,8 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
               const DevObs& O = obs[ob];
               to_box_frame(O, pc, t);
               box_rel(O, PR, Rr);
-              const double g = box_box_sat<true>(t, Rr, a, O.h, best * (1.0 + 1e-15) + 1e-300);
-              if (g > 0.0 && g <= best) {
+              const double g = box_box_sat<true>(t, Rr, a, O.h, best + kSatSlack);
+              if (g > 0.0 && g <= best + kSatSlack) {  // (kSatSlack: the minimum does not depend on the order of the pairs)
                 need = true;
                 ob_n = ob;
               }
@@ -3862,6 +3954,285 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   if (in_range && A.av_ok) A.av_ok[gi] = ok ? 1 : 0;
 }
 
+// The avoidance rows for the one state a QP iteration of the differential-kinematics planner asks about
+// (collision_avoidance.cpp:102-277 runs once per iteration), and for small batches: a wave per state, as
+// distance_small_kernel.  Lane (qi, part) scans every K-th box of the candidates of primitive qi, K = 64 / P; the K
+// partial results of a primitive are merged through LDS by (distance, box id), which is the oracle's "first minimum
+// in ascending box order"; lane (qi, 0) then builds the row.  Candidates: the avoidance grid's cell list of the
+// primitive's centre, complete within its radius; a primitive whose nearest listed box is farther than that (or
+// that has none) goes over all boxes.  Exact closest points by the whole wave (exact_cp_wave_ab).
+template <int ROBOT, int NL>
+__global__ void __launch_bounds__(kBlock)
+avoid_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                   const DevObs* __restrict__ obs) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint, W = 6 + NJ;
+  constexpr int kRed = 8;  // doubles per lane in the merge: distance, box id, the two points
+  __shared__ double sm_item[(kBlock / 64) * kCpBatch * kExactItemAB];
+  __shared__ unsigned long long sm_res[(kBlock / 64) * kCpBatch];
+  __shared__ double sm_s2[(kBlock / 64) * 24 * kCpBatch];
+  __shared__ unsigned sm_win[(kBlock / 64) * kCpBatch];
+  __shared__ double sm_red[(kBlock / 64) * 64 * kRed];
+  constexpr int kSweepKeep = 24;  // boxes a lane keeps per round of the sweep over all boxes
+  __shared__ unsigned short sm_keep[(kBlock / 64) * kSweepKeep * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  lds_ushort* keep = (lds_ushort*)sm_keep + wv * kSweepKeep * 64;
+  lds_double* ex_item = (lds_double*)sm_item + wv * kCpBatch * kExactItemAB;
+  lds_u64* ex_res = (lds_u64*)sm_res + wv * kCpBatch;
+  lds_double* ex_s2 = (lds_double*)sm_s2 + wv * 24 * kCpBatch;
+  lds_uint* ex_win = (lds_uint*)sm_win + wv * kCpBatch;
+  lds_double* red = (lds_double*)sm_red + wv * 64 * kRed;
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * (kBlock / 64) + static_cast<uint64_t>(wv);
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, false, true>(A, li, st, edge, step);
+  double Rw[9];
+  quat_to_mat(st[3], st[4], st[5], st[6], Rw);
+  double cs[2 * NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) sincos_cw(st[7 + j], cs[2 * j + 1], cs[2 * j]);
+
+  const int P = M->n_prim;
+  const int K = 64 / P;  // >= 2 (P <= MVK_MAX_PRIM = 32)
+  const bool active = in_range && lane < P * K;
+  const int qi = lane % P, part = lane / P;
+  const int q = X->prim_order[qi];
+  int myk = 0;
+#pragma unroll 1
+  for (int k = 1; k < S::kSeg; ++k) myk = qi >= X->seg_prim_begin[k] ? k : myk;
+  double R[9], p[3] = {st[0], st[1], st[2]};
+#pragma unroll
+  for (int c = 0; c < 9; ++c) R[c] = Rw[c];
+  static_for<1, S::kSeg>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if (k <= myk) {
+      double pn[3];
+      xform(R, p, M->seg_t[k][0], M->seg_t[k][1], M->seg_t[k][2], pn);
+      p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+      rot_cols<S::axis(k)>(R, cs[2 * S::joint(k)], cs[2 * S::joint(k) + 1]);
+    }
+  });
+  double pc[3], PR[9];
+  prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
+  const int type = M->prim_type[q];
+  const double rb = X->prim_bound[q];
+  const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+  const double a[3] = {d0, d1, d2};
+
+  // this lane's best so far; `cut` also knows the primitive's best after a merge (pruning only)
+  double best = INFINITY, cut = INFINITY, br[3] = {NAN, NAN, NAN}, be[3] = {NAN, NAN, NAN};
+  int bi = -1;
+  auto take = [&](double d, int ob, const double pr[3], const double pq[3]) {  // points in the frame of box ob
+    if (d < best || (d == best && ob < bi)) {
+      const DevObs& O = obs[ob];
+      best = d;
+      bi = ob;
+      cut = fmin(cut, d);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {  // box frame -> world (NaN points stay NaN)
+        br[c] = fma(O.R[3 * c], pr[0], fma(O.R[3 * c + 1], pr[1], fma(O.R[3 * c + 2], pr[2], O.c[c])));
+        be[c] = fma(O.R[3 * c], pq[0], fma(O.R[3 * c + 1], pq[1], fma(O.R[3 * c + 2], pq[2], O.c[c])));
+      }
+    }
+  };
+  const double nan3[3] = {NAN, NAN, NAN};
+  // one box for this lane (kGridNone: none), by the whole wave: the exact stage is shared
+  auto process = [&](int ob) {
+    bool need = false, reach = false;
+    double Rr[9], t[3] = {0.0, 0.0, 0.0}, h[3] = {0.0, 0.0, 0.0};
+    if (ob != kGridNone) {
+      to_box_frame(obs[ob], pc, t);
+      const double l2 = point_box_dist2(t, obs[ob].h);
+      const double thr = rb + fmax(cut, 0.0) + kSatSlack;  // centre distance - bounding radius bounds the pair from below
+      reach = l2 <= thr * thr * (1.0 + 1e-12);
+    }
+    if (!__any(reach)) return;  // (most rounds of a sweep over all boxes)
+    if (ob != kGridNone) {
+      const DevObs& O = obs[ob];
+      if (reach) {
+        if (type == MVK_PRIM_BOX) {
+          box_rel(O, PR, Rr);
+          h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
+          const double g = box_box_sat<true>(t, Rr, a, h, cut + kSatSlack);
+          if (g <= 0.0) take(g, ob, nan3, nan3);  // in contact: no points
+          else need = g <= cut + kSatSlack;
+        } else {
+          double pr[3], pq[3];
+          const double d = narrow_cp(type, PR, d0, d1, d2, O, t, pr, pq, cut);
+          take(d, ob, pr, pq);
+        }
+      }
+    }
+    double pr[3], pq[3];
+    const double d = exact_cp_wave_ab(ex_item, ex_res, ex_s2, ex_win, need, Rr, t, h, a, pr, pq);
+    if (need) take(d, ob, pr, pq);
+  };
+  auto scan = [&](const uint16_t* __restrict__ ids, int n_items) {  // ids == nullptr: boxes 0 .. n_items-1
+#pragma unroll 1
+    for (int e = part; __any(e < n_items); e += K) process(e < n_items ? (ids ? static_cast<int>(ids[e]) : e) : kGridNone);
+  };
+  // merge of the K partial results of a primitive: every lane learns its primitive's best distance (`cut`); lane
+  // (qi, 0) takes the winner's record
+  auto merge = [&](bool final_round) {
+    red[lane * kRed + 0] = best;
+    red[lane * kRed + 1] = static_cast<double>(bi);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { red[lane * kRed + 2 + c] = br[c]; red[lane * kRed + 5 + c] = be[c]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double mb = INFINITY;
+    int mi = -1, ml = lane;
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+      const int l = qi + j * P;
+      const double d = red[l * kRed + 0];
+      const int b = static_cast<int>(red[l * kRed + 1]);
+      if (b >= 0 && (mi < 0 || d < mb || (d == mb && b < mi))) { mb = d; mi = b; ml = l; }
+    }
+    cut = fmin(cut, mb);
+    if (final_round && part == 0 && mi >= 0) {
+      best = mb;
+      bi = mi;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { br[c] = red[ml * kRed + 2 + c]; be[c] = red[ml * kRed + 5 + c]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  bool todo = active;  // primitives whose candidates are not complete yet
+  if (A.dgrid.start != nullptr) {
+    unsigned gb, ge;
+    grid_cell(A.dgrid, pc, active, gb, ge);
+    scan(A.dgrid.items + static_cast<size_t>(gb) * kGridGroup, static_cast<int>(ge - gb) * kGridGroup);
+    merge(false);
+    todo = active && !(rb + fmax(cut, 0.0) + 2.0 * kSatSlack <= A.dgrid_radius);
+  }
+  if (__any(todo)) {
+    // The sweep over all boxes.  First the box nearest to the primitive's centre: its distance bounds the primitive's
+    // from above.  Then the boxes whose centre distance can undercut that are collected per lane (a cheap pass:
+    // one in a few dozen survives) and only those go through the narrowphase, which the wave runs in lockstep.
+    double l2min = INFINITY;
+    int emin = -1;
+#pragma unroll 1
+    for (int e = part; __any(todo && e < A.n_obs); e += K)
+      if (todo && e < A.n_obs) {
+        double t[3];
+        to_box_frame(obs[e], pc, t);
+        const double l2 = point_box_dist2(t, obs[e].h);
+        if (l2 < l2min) { l2min = l2; emin = e; }
+      }
+    red[lane * kRed] = l2min;
+    red[lane * kRed + 1] = static_cast<double>(emin);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+      const double l2 = red[(qi + j * P) * kRed];
+      if (l2 < l2min) { l2min = l2; emin = static_cast<int>(red[(qi + j * P) * kRed + 1]); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (todo) cut = fmin(cut, sqrt(l2min) * (1.0 + 1e-12));
+    process(todo && part == 0 ? emin : kGridNone);  // (emin >= 0: the scene is not empty)
+    merge(false);
+    int e = part;
+#pragma unroll 1
+    while (__any(todo && e < A.n_obs)) {
+      int cnt = 0;
+      const double thr = rb + fmax(cut, 0.0) + kSatSlack;
+      const double thr2 = thr * thr * (1.0 + 1e-12);
+#pragma unroll 1
+      while (__any(todo && e < A.n_obs && cnt < kSweepKeep)) {
+        if (todo && e < A.n_obs && cnt < kSweepKeep) {
+          double t[3];
+          to_box_frame(obs[e], pc, t);
+          if (point_box_dist2(t, obs[e].h) <= thr2) {
+            keep[cnt * 64 + lane] = static_cast<unsigned short>(e);
+            ++cnt;
+          }
+          e += K;
+        }
+      }
+#pragma unroll 1
+      for (int i = 0; __any(i < cnt); ++i) process(i < cnt ? static_cast<int>(keep[i * 64 + lane]) : kGridNone);
+      merge(false);
+    }
+  }
+  merge(true);
+
+  const bool report = active && part == 0;
+  const bool usable = bi >= 0 && best > 0.0;
+  const bool okq = bi < 0 || best > 0.0;
+  const bool ok = !__any(report && !okq);
+  if (report) {
+    // normal from the environment to the robot, and the row over the chain up to this segment (as avoid_kernel)
+    double nrm[3] = {br[0] - be[0], br[1] - be[1], br[2] - be[2]};
+    const double inv = 1.0 / sqrt(fma(nrm[0], nrm[0], fma(nrm[1], nrm[1], nrm[2] * nrm[2])));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nrm[c] = usable ? nrm[c] * inv : 0.0;
+    double row[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) row[c] = 0.0;
+    if (A.av_full_body) {
+      const double rx = br[0] - st[0], ry = br[1] - st[1], rz = br[2] - st[2];
+      row[0] = nrm[0]; row[1] = nrm[1]; row[2] = nrm[2];
+      row[3] = usable ? fma(ry, nrm[2], -rz * nrm[1]) : 0.0;
+      row[4] = usable ? fma(rz, nrm[0], -rx * nrm[2]) : 0.0;
+      row[5] = usable ? fma(rx, nrm[1], -ry * nrm[0]) : 0.0;
+    }
+    {
+      double Rj[9], pj[3];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) Rj[c] = Rw[c];
+      pj[0] = st[0]; pj[1] = st[1]; pj[2] = st[2];
+      static_for<1, S::kSeg>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
+        if (s <= myk) {
+          double pn[3];
+          xform(Rj, pj, M->seg_t[s][0], M->seg_t[s][1], M->seg_t[s][2], pn);
+          pj[0] = pn[0]; pj[1] = pn[1]; pj[2] = pn[2];
+          constexpr int ax = S::axis(s);
+          const double ax_w[3] = {Rj[ax], Rj[3 + ax], Rj[6 + ax]};
+          const double rx = br[0] - pj[0], ry = br[1] - pj[1], rz = br[2] - pj[2];
+          const double vx = fma(ax_w[1], rz, -ax_w[2] * ry), vy = fma(ax_w[2], rx, -ax_w[0] * rz),
+                       vz = fma(ax_w[0], ry, -ax_w[1] * rx);
+          row[6 + S::joint(s)] = usable ? fma(nrm[0], vx, fma(nrm[1], vy, nrm[2] * vz)) : 0.0;
+          rot_cols<ax>(Rj, cs[2 * S::joint(s)], cs[2 * S::joint(s) + 1]);
+        }
+      });
+    }
+    if (A.av_dist) A.av_dist[q * A.ld + gi] = best;
+    if (A.av_box) A.av_box[q * A.ld + gi] = bi;
+    if (A.av_lb)
+      A.av_lb[q * A.ld + gi] = (usable && best < A.av_range) ? -A.av_gain * ((best - A.av_forbid) / (A.av_range - A.av_forbid)) : -1e6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (A.av_p_env) A.av_p_env[(3 * q + c) * A.ld + gi] = usable ? be[c] : NAN;
+      if (A.av_p_robot) A.av_p_robot[(3 * q + c) * A.ld + gi] = usable ? br[c] : NAN;
+    }
+    if (A.av_row) {
+#pragma unroll
+      for (int c = 0; c < W; ++c) A.av_row[(static_cast<uint64_t>(W) * q + c) * A.ld + gi] = row[c];
+    }
+  }
+  if (in_range && lane == 0 && A.av_ok) A.av_ok[gi] = ok ? 1 : 0;
+  if (A.host_done) {  // as distance_small_kernel: the last block raises the pinned done word
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence_system();
+      const unsigned before = atomicAdd(A.fused_done, 1u);
+      if (before + 1u == A.small_target) {
+        __threadfence_system();
+        *A.host_done = A.fused_seq;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------
 // small helper kernels
 // ------------------------------------------------------------------------
@@ -4018,6 +4389,15 @@ int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, 
 
 int launch_avoid(const EvalArgs& a, int robot_type, int n_links, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.small_full) {  // a wave per state
+    const dim3 gs(static_cast<unsigned>((a.n + (kBlock / 64) - 1) / (kBlock / 64))), bs(kBlock);
+    if (robot_type == MVK_ROBOT_HYDRUS && n_links == 4) hipLaunchKernelGGL((avoid_small_kernel<MVK_ROBOT_HYDRUS, 4>), gs, bs, 0, s, a, a.model, a.extras, a.obs);
+    else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 6) hipLaunchKernelGGL((avoid_small_kernel<MVK_ROBOT_HYDRUS, 6>), gs, bs, 0, s, a, a.model, a.extras, a.obs);
+    else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 8) hipLaunchKernelGGL((avoid_small_kernel<MVK_ROBOT_HYDRUS, 8>), gs, bs, 0, s, a, a.model, a.extras, a.obs);
+    else if (robot_type == MVK_ROBOT_DRAGON && n_links == 4) hipLaunchKernelGGL((avoid_small_kernel<MVK_ROBOT_DRAGON, 4>), gs, bs, 0, s, a, a.model, a.extras, a.obs);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   const uint64_t blocks = (a.n + kBlock - 1) / kBlock;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;

@@ -111,3 +111,27 @@ def test_many_small_full_calls_in_a_row_keep_their_answers_apart():
             f = eng.is_valid_batch(w.soa[:, a:a + n], w.layout)["flags"]
             assert np.array_equal(f, big["flags"][a:a + n]), (it, n, a)
     eng.close()
+
+
+@pytest.mark.parametrize("name,model,boxes,params,soa,layout", list(_workloads()), ids=lambda v: v if isinstance(v, str) else "")
+def test_avoidance_rows_wave_per_state_equal_lane_per_state(monkeypatch, name, model, boxes, params, soa, layout):
+    """collision-avoidance rows (collision_avoidance.cpp:102-277): up to 4096 states per call take avoid_small_kernel
+    (a wave per state; host calls of up to 256 states through pinned memory and the done word); every output must
+    equal avoid_kernel's bit for bit, and the oracle's within the tolerances of test_gpu_avoid.py"""
+    soa = soa[:, :1024]
+    sizes = (1, 2, 5, 64, 256, 257, 1024)
+    out = {}
+    for small in (True, False):
+        if not small:
+            monkeypatch.setenv("MVK_NO_SMALL_FULL", "1")
+        eng = mp.Engine(model, boxes, params)
+        out[small] = [eng.collision_avoidance_batch(soa[:, :n], layout) for n in sizes]
+        eng.close()
+    for a, b, n in zip(out[True], out[False], sizes):
+        for key in ("dist", "box", "p_env", "p_robot", "row", "lb", "ok"):
+            assert np.array_equal(a[key], b[key], equal_nan=(a[key].dtype.kind == "f")), (name, n, key)
+    ref = O.avoid_batch(model, boxes, params, soa[:, :256])
+    got = out[True][4]
+    assert np.allclose(got["dist"], ref["dist"], rtol=1e-5, atol=1e-9)
+    tie = np.abs(got["dist"] - ref["dist"]) > 0
+    assert np.all((got["box"] == ref["box"]) | tie) and np.array_equal(got["ok"], ref["ok"])
