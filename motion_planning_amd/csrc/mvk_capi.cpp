@@ -1352,13 +1352,22 @@ extern "C" int mvk_collision_avoidance_batch(mvk_ctx* c, const double* soa, size
     mvk_avoid_out d{static_cast<double*>(pd[0]), static_cast<int32_t*>(pd[1]), static_cast<double*>(pd[2]), static_cast<double*>(pd[3]),
                     static_cast<double*>(pd[4]), static_cast<double*>(pd[5]), static_cast<uint8_t*>(pd[6])};
     const uint32_t seq = next_seq(c);
+    static const bool trace = std::getenv("MVK_TRACE_SMALL") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     if (int rc = run_avoid_dev(c, up, n, dld, layout, prm, &d, s, seq)) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     int gave_up = 0;
     if (int rc = fused_wait(c, seq, s, &gave_up)) return rc;
+    const auto t2 = std::chrono::steady_clock::now();
     for (int k = 0; k < 7; ++k)
       if (host[k])
         for (size_t r = 0; r < nrows[k]; ++r)
           std::memcpy(static_cast<unsigned char*>(host[k]) + r * ld * elem[k], static_cast<unsigned char*>(pd[k]) + r * dld * elem[k], n * elem[k]);
+    if (trace) {
+      const auto t3 = std::chrono::steady_clock::now();
+      auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      std::fprintf(stderr, "mvk: avoidance rows n=%zu: launch %.1f us, wait %.1f us, copy out %.1f us\n", n, us(t0, t1), us(t1, t2), us(t2, t3));
+    }
     return MVK_OK;
   }
   if (int rc = c->in_a.reserve(dld * rows * sizeof(double))) return rc;
