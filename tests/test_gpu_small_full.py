@@ -1,5 +1,5 @@
 """Full path (verdict + exact minimum distance + margin + band + statistics) on small batches: up to 4096 states per
-call go through distance_small_kernel (a group of 32 lanes per state, one lane per primitive and list slice) instead
+call go through distance_small_kernel (a wave per state, one lane per primitive and list slice) instead
 of distance_kernel (one lane per state); MVK_NO_SMALL_FULL=1 keeps the latter.  Both take the minimum of the same
 per-pair values, so every output must carry the same bits, and both must agree with the oracle.
 
