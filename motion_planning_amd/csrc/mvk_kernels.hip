@@ -1904,9 +1904,10 @@ DEV void dist_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const Sme
     wt = sm.dring[5 * kRing + at];
   }
   const unsigned g0 = wa & 0x1FFFFFu, src = (wa >> 21) & 63u, slot = (wa >> 27) & 15u;
-  const bool all = wa >> 31;
+  const bool all = wa >> 31, wide = wb >> 31;  // the range's kind: all boxes in order / a cell of the wider second grid / a cell of the grid
+  const unsigned ge = wb & 0x7FFFFFFFu;
   const unsigned g = g0 + sub;
-  if (active && g < wb) {
+  if (active && g < ge) {
     unsigned ids[kGridGroup];
     if (all) {
 #pragma unroll
@@ -1915,7 +1916,7 @@ DEV void dist_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const Sme
         ids[e] = id < static_cast<unsigned>(A.n_obs) ? id : static_cast<unsigned>(kGridNone);
       }
     } else {
-      const uint2 w = *reinterpret_cast<const uint2*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
+      const uint2 w = *reinterpret_cast<const uint2*>((wide ? A.dgrid2.items : A.dgrid.items) + static_cast<size_t>(g) * kGridGroup);
       ids[0] = w.x & 0xFFFFu; ids[1] = w.x >> 16; ids[2] = w.y & 0xFFFFu; ids[3] = w.y >> 16;
     }
     DevObsF F[kGridGroup];
@@ -1941,7 +1942,7 @@ DEV void dist_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const Sme
                              __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
   }
-  const bool more = active && sub == 0u && g0 + rep < wb;  // the item's owner lane puts the rest of the range back
+  const bool more = active && sub == 0u && g0 + rep < ge;  // the item's owner lane puts the rest of the range back
   head = (head + m) & (kRing - 1);
   qn -= m;
   const unsigned long long bal = __ballot(more);
@@ -1960,7 +1961,9 @@ DEV void dist_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const Sme
 }
 
 // one item per lane that wants one (wave-uniform head / qn)
-DEV void dist_push(const Smem& sm, bool want, const double pc[3], unsigned gb, unsigned ge, unsigned slot, bool all, float thr2,
+// kind of a range: a cell of the distance grid, a cell of the wider second grid, all boxes in order
+constexpr unsigned kRangeCell = 0u, kRangeWide = 1u, kRangeAll = 2u;
+DEV void dist_push(const Smem& sm, bool want, const double pc[3], unsigned gb, unsigned ge, unsigned slot, unsigned kind, float thr2,
                    unsigned head, unsigned& qn) {
   const int lane = threadIdx.x & 63;
   const bool push = want && gb < ge;
@@ -1971,8 +1974,8 @@ DEV void dist_push(const Smem& sm, bool want, const double pc[3], unsigned gb, u
       sm.dring[0 * kRing + to] = __float_as_uint(static_cast<float>(pc[0]));
       sm.dring[1 * kRing + to] = __float_as_uint(static_cast<float>(pc[1]));
       sm.dring[2 * kRing + to] = __float_as_uint(static_cast<float>(pc[2]));
-      sm.dring[3 * kRing + to] = gb | (static_cast<unsigned>(lane) << 21) | (slot << 27) | (all ? 1u << 31 : 0u);
-      sm.dring[4 * kRing + to] = ge;
+      sm.dring[3 * kRing + to] = gb | (static_cast<unsigned>(lane) << 21) | (slot << 27) | (kind == kRangeAll ? 1u << 31 : 0u);
+      sm.dring[4 * kRing + to] = ge | (kind == kRangeWide ? 1u << 31 : 0u);
       sm.dring[5 * kRing + to] = __float_as_uint(thr2);
     }
     qn += static_cast<unsigned>(__popcll(bal));
@@ -2005,6 +2008,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
   const DevObsF* __restrict__ obsf = A.obsf;
   const double delta = static_cast<double>(A.f32_delta), dd = 2.0 * delta;
   const unsigned groups_all = static_cast<unsigned>((A.n_obs + kGridGroup - 1) / kGridGroup);
+  const bool have_wide = A.dgrid2.start != nullptr && A.dgrid2_radius > A.dgrid_radius;
   lds_uint* up_bits = reinterpret_cast<lds_uint*>(sm.upper);
   unsigned head = 0, qn = 0;  // the wave's ring (wave-uniform)
   if (use_grid) {
@@ -2029,7 +2033,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
           rb_max = fmax(rb_max, X->prim_bound[q]);
           unsigned gb = 0, ge = groups_all;
           if (!all_boxes) grid_cell(A.dgrid, pc, who, gb, ge);
-          dist_push(sm, who, pc, gb, ge, static_cast<unsigned>(qi < kUpperSlots ? qi : kUpperSlots - 1), all_boxes, 0.0f, head, qn);
+          dist_push(sm, who, pc, gb, ge, static_cast<unsigned>(qi < kUpperSlots ? qi : kUpperSlots - 1), all_boxes ? kRangeAll : kRangeCell, 0.0f, head, qn);
 #pragma unroll 1
           while (qn >= 64u) dist_pop<false>(A, obsf, sm, head, qn);
         }
@@ -2086,9 +2090,15 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
         // that (the bound still loose, the robot far from every box, or outside the grid's volume) takes ALL boxes as
         // its range: first their smallest centre distance, which tightens the bound, then the collection
         const bool far = on && !(thr0 + dd <= A.dgrid_radius);
+        // ... unless the wider second grid (the avoidance rows' one) can answer: its cell's list is a few dozen boxes
+        unsigned far_b = 0u, far_e = groups_all, far_kind = kRangeAll;
         if (__any(far)) {
+          if (far && have_wide && thr0 + dd <= A.dgrid2_radius) {
+            grid_cell(A.dgrid2, pc, true, far_b, far_e);
+            far_kind = kRangeWide;
+          }
           if (far) *up_slot = 0x7F800000u;
-          dist_push(sm, far, pc, 0u, groups_all, static_cast<unsigned>(qi < kUpperSlots ? qi : kUpperSlots - 1), true, 0.0f, head, qn);
+          dist_push(sm, far, pc, far_b, far_e, static_cast<unsigned>(qi < kUpperSlots ? qi : kUpperSlots - 1), far_kind, 0.0f, head, qn);
 #pragma unroll 1
           while (qn > 0u) dist_pop<false>(A, obsf, sm, head, qn);
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2109,7 +2119,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
         const float tf = (static_cast<float>(thr0) + A.f32_delta) * 1.000001f;
         sm.dcnt[lane] = 0u;
         if (!far) grid_cell(A.dgrid, pc, want, cell_b, cell_e);
-        dist_push(sm, want, pc, far ? 0u : cell_b, far ? groups_all : cell_e, 0u, far, tf * tf, head, qn);
+        dist_push(sm, want, pc, far ? far_b : cell_b, far ? far_e : cell_e, 0u, far ? far_kind : kRangeCell, tf * tf, head, qn);
 #pragma unroll 1
         while (qn > 0u) dist_pop<true>(A, obsf, sm, head, qn);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
