@@ -390,8 +390,9 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
   }
   std::sort(dist.begin(), dist.end());
   for (int g = 0; g < 2; ++g) {
-    int pct = g == 0 ? 60 : 95;
+    int pct = g == 0 ? 25 : 95;  // (profiles/pct_sweep.sh: with the second grid behind it the first one pays off small)
     if (const char* ov = std::getenv("MVK_DISTANCE_GRID_PCT")) if (std::atoi(ov) > 0 && std::atoi(ov) < 100) pct = std::atoi(ov);  // diagnostics
+    if (g == 1) if (const char* ov = std::getenv("MVK_DISTANCE_GRID_PCT2")) if (std::atoi(ov) > 0 && std::atoi(ov) < 100) pct = std::atoi(ov);
     double slack = std::fmin(std::fmax(dist[(kProbe * pct) / 100], 0.05), 4.0);
     GridHost gh;
     bool built = false;
