@@ -486,6 +486,10 @@ struct Smem {
   // full path, distance kernel: this wave's broadphase ring [kDRingWords][kRing] and its lanes' candidate counts [64]
   lds_uint* dring;
   lds_uint* dcnt;
+  // full path, flat drain: per lane of this wave the running minimum as an ordered key [64], and the smallest pending
+  // separating-axis gap of the round [64]
+  lds_u64* mres;
+  lds_u64* gmin;
 };
 #ifndef MVK_UPPER_SLOTS
 #define MVK_UPPER_SLOTS 16
@@ -1982,6 +1986,15 @@ DEV void dist_push(const Smem& sm, bool want, const double pc[3], unsigned gb, u
   }
 }
 
+// doubles as unsigned keys that order like the values (negative ones included), for LDS atomic minima
+DEV unsigned long long ord_key(double x) {
+  const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(x));
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+DEV double ord_val(unsigned long long k) {
+  return __longlong_as_double(static_cast<long long>((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
+
 // ------------------------------------------------------------------------
 // full path: exact minimum distance over every (primitive, box) pair
 // ------------------------------------------------------------------------
@@ -2074,11 +2087,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
       bool swept = false;
       unsigned cell_b = 0, cell_e = 0;  // the grid cell's groups, when the candidates came from it
       if (use_grid) {
-#ifdef MVK_EXP_DECOUPLE
-        const double bound = upper;
-#else
         const double bound = fmin(mind, upper);
-#endif
         // the first walk's minimum for this primitive: when even its nearest box (of a list that is complete for the
         // threshold) is too far to undercut the bound -- lower bound: centre distance - bounding radius -- there is
         // nothing to collect: most primitives of a state, since only the few nearest matter
@@ -2107,11 +2116,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
             const double est = static_cast<double>(sqrtf(__uint_as_float(*up_slot)));
             up_q = est * 0.999999;
             upper = fmin(upper, est * 1.000001 + delta);
-#ifdef MVK_EXP_DECOUPLE
-            thr0 = rb + fmax(upper, 0.0);
-#else
             thr0 = rb + fmax(fmin(mind, upper), 0.0);
-#endif
           }
         }
         const bool none = (qi < kUpperSlots || far) && on && up_q - delta > thr0 + dd;
@@ -2186,7 +2191,123 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
         // their lists with the bound alone, each stopping at its next candidate that does need the exact
         // distance; the wave then computes those together (below).
         const double a[3] = {d0, d1, d2};
-        int e = 0;
+        // Flat drain (no lane's list overflowed, the common case): the lists of a primitive step have very different
+        // lengths -- two candidates on average, ten in the longest of 64 -- so instead of every lane scanning its
+        // own, the wave numbers the (lane, candidate) pairs through and takes them 64 at a time: a lane fetches the
+        // owner's pose and running minimum (cross-lane reads), computes the gap, and merges contacts and exact
+        // distances into the owner's minimum with LDS atomics on ordered keys.  Per round the pair with the smallest
+        // gap of each owner gets its exact distance first; the others are re-tested against the result.
+        const bool flat = use_grid && !__any(live && overflow);
+        if (flat) {
+          const int wave_tid = tid - lane;
+          unsigned incl = static_cast<unsigned>(todo);
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+          }
+          const unsigned T = __shfl(incl, 63);
+          sm.dcnt[lane] = incl;
+          sm.mres[lane] = ord_key(mind);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          // the exact distances of the pairs `mine`, kExactBatch at a time over the whole wave (see below), merged
+          // into the owner's minimum
+          auto run_exact = [&](bool want, int src, const double Rr[9], const double t[3], const double h[3]) {
+            unsigned long long pend = __ballot(want);
+#pragma unroll 1
+            while (pend) {
+              const int rank = __popcll(pend & ((1ull << lane) - 1ull));
+              const bool mine = want && ((pend >> lane) & 1ull) && rank < kExactBatch;
+              const int E = min(static_cast<int>(__popcll(pend)), kExactBatch);
+              if (mine) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) sm.ex_item[rank * kExactItem + c] = Rr[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { sm.ex_item[rank * kExactItem + 9 + c] = t[c]; sm.ex_item[rank * kExactItem + 12 + c] = h[c]; }
+                sm.ex_res[rank] = 0x7FF0000000000000ull;  // +inf
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+              for (int it = lane; it < 24 * E; it += 64) {
+                const int pr = it / 24, ed = it - 24 * pr;
+                double iR[9], it_[3], ih[3];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) iR[c] = sm.ex_item[pr * kExactItem + c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { it_[c] = sm.ex_item[pr * kExactItem + 9 + c]; ih[c] = sm.ex_item[pr * kExactItem + 12 + c]; }
+                const bool second = ed >= 12;
+                double cR[9], cc[3], ca[3], cb[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                  for (int c = 0; c < 3; ++c) cR[3 * r + c] = second ? iR[3 * c + r] : iR[3 * r + c];
+                  const double tb = -fma(iR[r], it_[0], fma(iR[3 + r], it_[1], iR[6 + r] * it_[2]));
+                  cc[r] = second ? tb : it_[r];
+                  ca[r] = second ? ih[r] : a[r];
+                  cb[r] = second ? a[r] : ih[r];
+                }
+                const double s2 = box_edge_to_box2(second ? ed - 12 : ed, cc, cR, ca, cb);
+                __hip_atomic_fetch_min(&sm.ex_res[pr], static_cast<unsigned long long>(__double_as_longlong(s2)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if (mine)
+                __hip_atomic_fetch_min(&sm.mres[src], ord_key(sqrt(__longlong_as_double(static_cast<long long>(sm.ex_res[rank])))),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              pend &= ~__ballot(mine);
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+          };
+#pragma unroll 1
+          for (unsigned base = 0; base < T; base += 64u) {
+            const unsigned i = base + static_cast<unsigned>(lane);
+            const bool act = i < T;
+            unsigned lo = 0u, hi = 63u;  // the owner: the first lane whose inclusive count exceeds i
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+              const unsigned mid = (lo + hi) >> 1;
+              if (sm.dcnt[mid] > i) hi = mid; else lo = mid + 1u;
+            }
+            const int src = act ? static_cast<int>(lo) : lane;
+            const unsigned e = i - (src > 0 ? sm.dcnt[src - 1] : 0u);
+            double spc[3], sPR[9];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) spc[c] = __shfl(pc[c], src);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sPR[c] = __shfl(PR[c], src);
+            bool need = false;
+            double Rr[9], t[3], h[3] = {0.0, 0.0, 0.0}, g = INFINITY;
+            sm.gmin[lane] = ~0ull;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (act) {
+              const int ob = sm.list[e * kBlock + wave_tid + src];
+              const DevObs& O = obs[ob];
+              to_box_frame(O, spc, t);
+              box_rel(O, sPR, Rr);
+              h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
+              const double cut = ord_val(sm.mres[src]) + kSatSlack;
+              g = box_box_sat<true>(t, Rr, a, h, cut);
+              if (g <= 0.0) __hip_atomic_fetch_min(&sm.mres[src], ord_key(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              else need = g < cut;
+              if (need) __hip_atomic_fetch_min(&sm.gmin[src], static_cast<unsigned long long>(__double_as_longlong(g)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool first = need && static_cast<unsigned long long>(__double_as_longlong(g)) == sm.gmin[src];
+            run_exact(first, src, Rr, t, h);
+            const bool again = need && !first && g < ord_val(sm.mres[src]) + kSatSlack;
+            run_exact(again, src, Rr, t, h);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          mind = ord_val(sm.mres[lane]);
+        }
+        int e = flat ? todo : 0;
 #pragma unroll 1
         while (__any(e < todo)) {
           bool need = false;
@@ -3281,13 +3402,16 @@ distance_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
   __shared__ float sm_upper[kUpperSlots * kBlock];
   __shared__ unsigned sm_dring[(kBlock / 64) * kDRingWords * kRing];
   __shared__ unsigned sm_dcnt[kBlock];
+  __shared__ unsigned long long sm_mres[kBlock];
+  __shared__ unsigned long long sm_gmin[kBlock];
   const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool in_range = gi < A.n;
   const uint64_t li = in_range ? gi : (A.n - 1);
   Smem sm{nullptr, (lds_ushort*)sm_list, (lds_double*)sm_ex_item + (threadIdx.x >> 6) * kExactBatch * kExactItem,
           (lds_u64*)sm_ex_res + (threadIdx.x >> 6) * kExactBatch, nullptr, nullptr, (lds_float*)sm_upper,
           A.full_rec, A.full_rec_ld, gi,   // (the record rows are written for every launched lane: gi, not li)
-          (lds_uint*)sm_dring + (threadIdx.x >> 6) * (kDRingWords * kRing), (lds_uint*)sm_dcnt + (threadIdx.x & ~63)};
+          (lds_uint*)sm_dring + (threadIdx.x >> 6) * (kDRingWords * kRing), (lds_uint*)sm_dcnt + (threadIdx.x & ~63),
+          (lds_u64*)sm_mres + (threadIdx.x & ~63), (lds_u64*)sm_gmin + (threadIdx.x & ~63)};
 
   double st[7 + NJ];
   uint64_t edge;
@@ -4147,7 +4271,7 @@ avoid_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevE
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (todo) cut = fmin(cut, sqrt(l2min) * (1.0 + 1e-12));
-    process(todo && part == 0 ? emin : kGridNone);  // (emin >= 0: the scene is not empty)
+    process(todo && part == 0 && emin >= 0 ? emin : kGridNone);  // (emin < 0: an empty scene)
     merge(false);
     int e = part;
 #pragma unroll 1
