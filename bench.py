@@ -161,6 +161,26 @@ def distance_path(eng, w, d_soa, dev):
                                "outputs": "per primitive: distance, nearest box and points, constraint row, bound"}}
 
 
+def single_calls(eng, w):
+    """host round trips of the calls a one-state-at-a-time caller makes (OMPL's isValid / clearance, one QP iteration
+    of the differential-kinematics planner): mean wall time per call over 200 calls on the bench workload's scene"""
+    import numpy as np
+    s = np.ascontiguousarray(w.soa[:, :1])
+    st = np.ascontiguousarray(w.soa[:, 0])
+
+    def per_call(fn, reps=200):
+        for _ in range(20):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps * 1e6
+    return {"unit": "us per call (host pointers, ctypes included)",
+            "is_valid_flag_batch_of_one": per_call(lambda: eng.is_valid_batch(s, w.layout)),
+            "is_valid_with_distance_and_margin_batch_of_one": per_call(lambda: eng.is_valid_batch(s, w.layout, want=("flags", "min_dist", "margin", "band"))),
+            "avoidance_rows_one_state": per_call(lambda: eng.collision_avoidance_batch(s, w.layout), reps=100)}
+
+
 def make_workload(name, n):
     import common
     if name == "c2":
@@ -537,6 +557,8 @@ def main():
             out["workloads"] = {k: workload_leg(k, n, dev) for k in ("c2", "c3", "c5") if k != args.workload}
         if not args.no_distance and world == 1 and not sweep:
             out["distance_path"] = distance_path(eng, w, d_soa, dev)
+        if not args.no_distance and world == 1 and not sweep:
+            out["single_calls"] = single_calls(eng, w)
         if not args.no_fp32 and world == 1 and not sweep:
             out["fp32_variant"] = fp32_variant(eng, w, d_soa, n, dev)
         print(json.dumps(out))
