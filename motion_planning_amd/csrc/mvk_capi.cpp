@@ -122,6 +122,7 @@ struct mvk_ctx {
   Buf small_done;                  // distance_small_kernel: blocks finished, over all polled calls (never reset)
   uint32_t small_total = 0;        // ... and the count the last polled call ends on
   bool tag_clear_needed = false;   // the call sequence number has wrapped since first_tag was last cleared
+  uint64_t flag_small_max = kFlagSmallMax;    // flag path: states per host call that get a block each (flag_small_kernel)
   uint64_t small_avoid_max = kSmallAvoidMax;  // the same for the avoidance rows (avoid_small_kernel)
   uint64_t small_full_max = kSmallFullMax;  // states per call up to which the full path takes distance_small_kernel
   bool small_full_enabled = true;  // full path: distance_small_kernel for small batches (MVK_NO_SMALL_FULL=1: never)
@@ -807,6 +808,7 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
   std::memset(c->pin_ctl.p, 0, 4096);
   if (const char* off = std::getenv("MVK_NO_SMALL_FULL")) c->small_full_enabled = off[0] != '1';  // diagnostics, tests
   if (const char* v = std::getenv("MVK_SMALL_FULL_MAX")) if (std::atoll(v) > 0) c->small_full_max = c->small_avoid_max = static_cast<uint64_t>(std::atoll(v));  // diagnostics
+  if (const char* v = std::getenv("MVK_FLAG_SMALL_MAX")) if (std::atoll(v) > 0 && std::atoll(v) <= 1024) c->flag_small_max = static_cast<uint64_t>(std::atoll(v));  // diagnostics
   if (const char* off = std::getenv("MVK_NO_FUSED")) c->fused_enabled = off[0] != '1';  // diagnostics: always two launches
   return c;
 }
@@ -1082,6 +1084,28 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
     for (int r = 0; r < rows; ++r) std::memcpy(up + static_cast<size_t>(r) * dld, soa + static_cast<size_t>(r) * ld, n * sizeof(double));
     EvalArgs a;
     base_args(c, a);
+    if (n <= c->flag_small_max && c->small_full_enabled) {
+      // a state or a few (OMPL's isValid): a block of two waves per state, walk 1 and the collision test side by side
+      a.soa = up;
+      a.n = n;
+      a.ld = dld;
+      a.layout = layout;
+      a.host_flags = static_cast<uint8_t*>(c->pin_down.p);
+      a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
+      a.fused_seq = next_seq(c);
+      a.fused_done = static_cast<uint32_t*>(c->small_done.p);
+      c->small_total += static_cast<uint32_t>(n);
+      a.small_target = c->small_total;
+      c->stats_valid = false;
+      const int e = launch_flag_small(a, c->model.robot_type, c->model.n_rotor, s);
+      if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+      c->timed = false;
+      if (int rc = leave_stream(c, s)) return rc;
+      int gave_up = 0;
+      if (int rc = fused_wait(c, a.fused_seq, s, &gave_up)) return rc;
+      std::memcpy(flags, c->pin_down.p, n);
+      return MVK_OK;
+    }
     a.soa = up;  // a few states: the kernel reads the pinned rows itself; more: one copy up first
     if (n > 1024) {
       HIP_TRY(hipMemcpyAsync(c->in_a.p, up, dld * rows * sizeof(double), hipMemcpyHostToDevice, s));

@@ -216,6 +216,7 @@ constexpr int kQueueCounterPitch = 64;  // uint32 words between two counters: on
 constexpr int kSmallGroup = 64;          // distance_small_kernel: lanes per state (>= MVK_MAX_PRIM)
 constexpr uint64_t kSmallFullMax = 4096;  // states per call up to which the full path takes distance_small_kernel (profiles/small_full_time.py)
 constexpr uint64_t kSmallAvoidMax = 4096; // ... and the avoidance rows avoid_small_kernel
+constexpr uint64_t kFlagSmallMax = 256;   // flag path: states per host call up to which a state gets a block of its own (flag_small_kernel)
 constexpr int kFusedMaxBlocks = 96;     // fused_kernel: every block resident at once (fewer than CUs); measured gain up to ~80 blocks (profiles/latency.py)
 
 
@@ -235,6 +236,7 @@ int static_scratch_for_current_device(int device, void** ptr);
 // events: nullptr, or hipEvent_t[3] recorded before / between / after the kernels of the call
 int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream, void* events);
 int launch_avoid(const EvalArgs& a, int robot_type, int n_links, void* stream);
+int launch_flag_small(const EvalArgs& a, int robot_type, int n_links, void* stream);
 int launch_edge_init(int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint64_t n_edges, void* stream);
 int launch_edge_finish(const int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint8_t* ok,
                        uint64_t n_edges, void* stream);

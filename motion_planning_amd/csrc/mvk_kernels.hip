@@ -4088,6 +4088,91 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   if (in_range && A.av_ok) A.av_ok[gi] = ok ? 1 : 0;
 }
 
+// Flag path for a handful of states (OMPL's isValid, one state per call): fused_kernel gives the state one lane, which
+// runs walk 1 and the collision walk one after the other -- 19 us for a single state.  Here a state has a block of
+// two waves that work side by side: wave 1 runs walk 1 (model_update, every lane the same state: a chain of dependent
+// fp64 that lanes cannot share), wave 0 the collision test as distance_small_kernel lays it out -- lane (qi, part)
+// walks the chain to the segment of primitive qi and tests every K-th box of that segment's cell of the flag grid
+// with exact_pair (fp64; the fp32 screen of the large kernels only ever removes pairs that cannot touch, so the
+// verdict is the same OR over the same exact tests).  Verdict to pinned host memory, done word by the last block.
+template <int ROBOT, int NL>
+__global__ void __launch_bounds__(128)
+flag_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                  const DevObs* __restrict__ obs) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ double sm_cs[2 * NJ * kBlock];  // model_update's cos/sin slots (pitch kBlock)
+  __shared__ unsigned sm_verdict[3];         // finite, stable, hit
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint64_t gi = blockIdx.x;            // one state per block (gridDim.x == A.n)
+  if (tid < 3) sm_verdict[tid] = 0u;
+  __syncthreads();
+
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, false, true>(A, gi, st, edge, step);
+  if (wv == 1) {
+    Smem sm{(lds_double*)sm_cs, nullptr};
+    StateOut o;
+    double Rw[9];
+    bool finite;
+    model_update<ROBOT, NL, false>(A, M, X, st, sm, gi, o, Rw, finite, nullptr);
+    if (lane == 0) {
+      sm_verdict[0] = finite ? 1u : 0u;
+      sm_verdict[1] = o.stable ? 1u : 0u;
+    }
+  } else if (A.do_coll && A.n_obs > 0) {
+    double cs[2 * NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) sincos_cw(st[7 + j], cs[2 * j + 1], cs[2 * j]);
+    double R[9], p[3] = {st[0], st[1], st[2]};
+    quat_to_mat(st[3], st[4], st[5], st[6], R);
+    const int P = M->n_prim;
+    const int K = 64 / P;
+    const bool active = lane < P * K;
+    const int qi = lane % P, part = lane / P;
+    const int q = X->prim_order[qi];
+    int myk = 0;
+#pragma unroll 1
+    for (int k = 1; k < S::kSeg; ++k) myk = qi >= X->seg_prim_begin[k] ? k : myk;
+    static_for<1, S::kSeg>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if (k <= myk) {
+        double pn[3];
+        xform(R, p, M->seg_t[k][0], M->seg_t[k][1], M->seg_t[k][2], pn);
+        p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+        rot_cols<S::axis(k)>(R, cs[2 * S::joint(k)], cs[2 * S::joint(k) + 1]);
+      }
+    });
+    // the segment's cell of the flag grid lists every box within the largest segment radius of the sphere's centre
+    double sc[3];
+    xform(R, p, X->seg_sph[myk][0], X->seg_sph[myk][1], X->seg_sph[myk][2], sc);
+    unsigned gb, ge;
+    grid_cell(A.grid, sc, active, gb, ge);
+    const int n_items = static_cast<int>(ge - gb) * kGridGroup;
+    const uint16_t* __restrict__ ids = A.grid.items + static_cast<size_t>(gb) * kGridGroup;
+    bool hit = false;
+#pragma unroll 1
+    for (int e = part; e < n_items && !hit; e += K) {
+      const int ob = ids[e];
+      if (ob != kGridNone) hit = exact_pair<S::kGimbal>(M, X, q, R, p, obs[ob]);
+    }
+    if (__any(hit) && lane == 0) sm_verdict[2] = 1u;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const bool valid = sm_verdict[0] != 0u && (!A.do_stab || sm_verdict[1] != 0u) && sm_verdict[2] == 0u;
+    A.host_flags[gi] = valid ? 1 : 0;
+    __threadfence_system();
+    const unsigned before = atomicAdd(A.fused_done, 1u);
+    if (before + 1u == A.small_target) {
+      __threadfence_system();
+      *A.host_done = A.fused_seq;
+    }
+  }
+}
+
 // The avoidance rows for the one state a QP iteration of the differential-kinematics planner asks about
 // (collision_avoidance.cpp:102-277 runs once per iteration), and for small batches: a wave per state, as
 // distance_small_kernel.  Lane (qi, part) scans every K-th box of the candidates of primitive qi, K = 64 / P; the K
@@ -4521,6 +4606,18 @@ int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, 
   return hipErrorInvalidValue;
 }
 
+int launch_flag_small(const EvalArgs& a, int robot_type, int n_links, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.n == 0) return hipSuccess;
+  if (a.n > 1024 || !a.host_flags || !a.host_done) return hipErrorInvalidValue;
+  const dim3 g(static_cast<unsigned>(a.n)), b(128);
+  if (robot_type == MVK_ROBOT_HYDRUS && n_links == 4) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_HYDRUS, 4>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 6) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_HYDRUS, 6>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 8) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_HYDRUS, 8>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else if (robot_type == MVK_ROBOT_DRAGON && n_links == 4) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_DRAGON, 4>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
 int launch_avoid(const EvalArgs& a, int robot_type, int n_links, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (a.small_full) {  // a wave per state

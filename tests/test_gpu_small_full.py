@@ -135,3 +135,28 @@ def test_avoidance_rows_wave_per_state_equal_lane_per_state(monkeypatch, name, m
     assert np.allclose(got["dist"], ref["dist"], rtol=1e-5, atol=1e-9)
     tie = np.abs(got["dist"] - ref["dist"]) > 0
     assert np.all((got["box"] == ref["box"]) | tie) and np.array_equal(got["ok"], ref["ok"])
+
+
+@pytest.mark.parametrize("name,model,boxes,params,soa,layout", list(_workloads()), ids=lambda v: v if isinstance(v, str) else "")
+def test_flag_calls_of_a_few_states_equal_the_fused_path(monkeypatch, name, model, boxes, params, soa, layout):
+    """OMPL's isValid (motion_planning.cpp:236: one state per call): host calls of up to 256 states give every state a
+    block of two waves (flag_small_kernel: walk 1 and the collision test side by side); same verdicts as the
+    lane-per-state kernels and as the oracle outside the band, over single calls and small batches"""
+    soa = soa[:, :600].copy()
+    soa[7, 5] = np.nan
+    ref = O.eval_batch(model, boxes, params, soa, layout, threads=8)
+    clear = ~ref["band"].astype(bool)
+    got = {}
+    for small in (True, False):
+        if not small:
+            monkeypatch.setenv("MVK_NO_SMALL_FULL", "1")
+        eng = mp.Engine(model, boxes, params)
+        singles = np.concatenate([eng.is_valid_batch(soa[:, i:i + 1], layout)["flags"] for i in range(300)])
+        chunks = np.concatenate([eng.is_valid_batch(soa[:, a:a + 16], layout)["flags"] for a in range(300, 332, 16)]
+                                + [eng.is_valid_batch(soa[:, 332:588], layout)["flags"], eng.is_valid_batch(soa[:, 588:600], layout)["flags"]])
+        got[small] = np.concatenate([singles, chunks])
+        eng.close()
+    assert np.array_equal(got[True], got[False])
+    assert np.array_equal(got[True][clear], ref["flags"][clear])
+    assert got[True][5] == 0
+    assert 0 < got[True].sum() < 600 or name.startswith("c2k far")
