@@ -11,6 +11,10 @@ import motion_planning_amd as mp
 model, params, boxes, start, goal = common.config1()
 eng = mp.Engine(model, boxes, params)
 rng = np.random.default_rng(0)
+# the first ~0.1 s of GPU work in a process runs several times slower (clocks, lazy loading): warm up first
+_w1 = np.tile(start[:, None], (1, 64)); _w2 = _w1 + 0.05
+for _ in range(1500):
+    eng.check_motion_batch(_w1, _w2, np.full(64, 41, np.int32))
 for E in ([int(x) for x in sys.argv[1:]] or [1, 64, 256, 1024]):
     s1 = np.tile(start[:, None], (1, E)) + rng.normal(scale=0.05, size=(6, E))
     s2 = s1 + rng.normal(scale=0.1, size=(6, E))
