@@ -1097,9 +1097,11 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
       c->small_total += static_cast<uint32_t>(n);
       a.small_target = c->small_total;
       c->stats_valid = false;
-      const int e = launch_flag_small(a, c->model.robot_type, c->model.n_rotor, s);
+      if (c->profiling) (void)hipEventRecord(c->ev[0], s);
+      const int e = launch_flag_small(a, c->model.robot_type, c->model.n_rotor, false, s);
       if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
-      c->timed = false;
+      if (c->profiling) { (void)hipEventRecord(c->ev[1], s); (void)hipEventRecord(c->ev[2], s); }
+      c->timed = c->profiling;
       if (int rc = leave_stream(c, s)) return rc;
       int gave_up = 0;
       if (int rc = fused_wait(c, a.fused_seq, s, &gave_up)) return rc;
@@ -1588,6 +1590,52 @@ extern "C" int mvk_check_motion_batch_begin(mvk_ctx* c, const double* s1, const 
   c->edges_have_nd = nd != nullptr;
   c->edges_nu = nu;
   c->edges_dld = dld;
+  if (fused_eligible(c, total) && nd_max < 0xFFFF && total <= c->flag_small_max && c->small_full_enabled) {
+    // an edge or a few (OMPL's checkMotion): a block of two waves per step (the blob goes to device memory first:
+    // lane -> (edge, step) -> rows is a chain of dependent reads, 2 us each over PCIe)
+    EvalArgs a;
+    base_args(c, a);
+    char* dev = static_cast<char*>(c->edge_blob.p);
+    a.edge_block = nd ? reinterpret_cast<const uint32_t*>(dev + off_blk) : nullptr;
+    a.s1 = reinterpret_cast<const double*>(dev);
+    a.s2 = reinterpret_cast<const double*>(dev + off_s2);
+    a.nd = nd ? reinterpret_cast<const int32_t*>(dev + off_nd) : nullptr;
+    a.edge_off = nd ? reinterpret_cast<const int64_t*>(dev + off_off) : nullptr;
+    a.nd_uniform = nu;
+    a.n = total;
+    a.n_edges = n_edges;
+    a.ld = dld;
+    a.layout = MVK_LAYOUT_OMPL;
+    c->stats_valid = false;
+    if (int rc = enter_stream(c, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(dev, up, bytes, hipMemcpyHostToDevice, s));
+    a.fused_seq = next_seq(c);
+    a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
+    {
+      const size_t before = c->first_tag.cap;
+      if (int rc = c->first_tag.reserve(n_edges * sizeof(uint32_t))) return rc;
+      if (c->tag_clear_needed || c->first_tag.cap != before) {
+        HIP_TRY(hipMemsetAsync(c->first_tag.p, 0, c->first_tag.cap, s));
+        c->tag_clear_needed = false;
+      }
+      a.first_tag = static_cast<uint32_t*>(c->first_tag.p);
+    }
+    a.host_first = static_cast<int32_t*>(c->pin_down.p);
+    a.fused_done = static_cast<uint32_t*>(c->small_done.p);
+    c->small_total += static_cast<uint32_t>(total);
+    a.small_target = c->small_total;
+    if (c->profiling) (void)hipEventRecord(c->ev[0], s);
+    const int e = launch_flag_small(a, c->model.robot_type, c->model.n_rotor, true, s);
+    if (e != hipSuccess) return fail(MVK_ERR_HIP, "edge kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+    if (c->profiling) { (void)hipEventRecord(c->ev[1], s); (void)hipEventRecord(c->ev[2], s); }
+    c->timed = c->profiling;
+    if (int rc = leave_stream(c, s)) return rc;
+    c->fused_in_flight = true;
+    c->edges_in_flight = n_edges;
+    c->edges_nd_off = off_nd;
+    c->edges_pending = true;
+    return MVK_OK;
+  }
   if (fused_eligible(c, total) && nd_max < 0xFFFF) {
     // one copy up (every lane of an edge reads the edge's rows: they belong in device memory, where the cache holds
     // them), one launch; the kernel leaves first_invalid in the pinned answer block and raises the done word

@@ -4095,7 +4095,10 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 // walks the chain to the segment of primitive qi and tests every K-th box of that segment's cell of the flag grid
 // with exact_pair (fp64; the fp32 screen of the large kernels only ever removes pairs that cannot touch, so the
 // verdict is the same OR over the same exact tests).  Verdict to pinned host memory, done word by the last block.
-template <int ROBOT, int NL>
+// EDGE: the states are the steps of a few edges (OMPL's checkMotion, one edge per call): block gi takes lane gi of
+// the flattened steps, an invalid step goes into the edge's tag word as in fused_kernel, the last block turns the tags
+// into first_invalid in the pinned answer block.
+template <int ROBOT, int NL, bool EDGE>
 __global__ void __launch_bounds__(128)
 flag_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
                   const DevObs* __restrict__ obs) {
@@ -4111,7 +4114,7 @@ flag_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevEx
   double st[7 + NJ];
   uint64_t edge;
   int step;
-  fetch_state<NJ, false, true>(A, gi, st, edge, step);
+  fetch_state<NJ, EDGE, true>(A, gi, st, edge, step);
   if (wv == 1) {
     Smem sm{(lds_double*)sm_cs, nullptr};
     StateOut o;
@@ -4161,12 +4164,33 @@ flag_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevEx
     if (__any(hit) && lane == 0) sm_verdict[2] = 1u;
   }
   __syncthreads();
-  if (tid == 0) {
-    const bool valid = sm_verdict[0] != 0u && (!A.do_stab || sm_verdict[1] != 0u) && sm_verdict[2] == 0u;
-    A.host_flags[gi] = valid ? 1 : 0;
-    __threadfence_system();
-    const unsigned before = atomicAdd(A.fused_done, 1u);
-    if (before + 1u == A.small_target) {
+  const bool valid = sm_verdict[0] != 0u && (!A.do_stab || sm_verdict[1] != 0u) && sm_verdict[2] == 0u;
+  if (!EDGE) {
+    if (tid == 0) {
+      A.host_flags[gi] = valid ? 1 : 0;
+      __threadfence_system();
+      const unsigned before = atomicAdd(A.fused_done, 1u);
+      if (before + 1u == A.small_target) {
+        __threadfence_system();
+        *A.host_done = A.fused_seq;
+      }
+    }
+  } else {
+    __shared__ unsigned sm_last;
+    if (tid == 0) {
+      if (!valid) mark_invalid_step(A, edge, step);
+      sm_last = __hip_atomic_fetch_add(A.fused_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == A.small_target ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!sm_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (uint64_t e = tid; e < A.n_edges; e += 128) {
+      const unsigned v = __hip_atomic_load(A.first_tag + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int nd_e = A.nd ? (A.nd[e] < 1 ? 1 : A.nd[e]) : A.nd_uniform;
+      A.host_first[e] = (v >> 16) == (A.fused_seq & 0xFFFFu) ? static_cast<int>(0xFFFFu - (v & 0xFFFFu)) : nd_e + 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
       __threadfence_system();
       *A.host_done = A.fused_seq;
     }
@@ -4606,17 +4630,21 @@ int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, 
   return hipErrorInvalidValue;
 }
 
-int launch_flag_small(const EvalArgs& a, int robot_type, int n_links, void* stream) {
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (a.n == 0) return hipSuccess;
-  if (a.n > 1024 || !a.host_flags || !a.host_done) return hipErrorInvalidValue;
+template <bool EDGE>
+int launch_flag_small_t(const EvalArgs& a, int robot_type, int n_links, hipStream_t s) {
   const dim3 g(static_cast<unsigned>(a.n)), b(128);
-  if (robot_type == MVK_ROBOT_HYDRUS && n_links == 4) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_HYDRUS, 4>), g, b, 0, s, a, a.model, a.extras, a.obs);
-  else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 6) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_HYDRUS, 6>), g, b, 0, s, a, a.model, a.extras, a.obs);
-  else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 8) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_HYDRUS, 8>), g, b, 0, s, a, a.model, a.extras, a.obs);
-  else if (robot_type == MVK_ROBOT_DRAGON && n_links == 4) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_DRAGON, 4>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  if (robot_type == MVK_ROBOT_HYDRUS && n_links == 4) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_HYDRUS, 4, EDGE>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 6) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_HYDRUS, 6, EDGE>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 8) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_HYDRUS, 8, EDGE>), g, b, 0, s, a, a.model, a.extras, a.obs);
+  else if (robot_type == MVK_ROBOT_DRAGON && n_links == 4) hipLaunchKernelGGL((flag_small_kernel<MVK_ROBOT_DRAGON, 4, EDGE>), g, b, 0, s, a, a.model, a.extras, a.obs);
   else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+int launch_flag_small(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.n == 0) return hipSuccess;
+  if (a.n > 1024 || !a.host_done || (edge_mode ? (!a.host_first || !a.first_tag) : !a.host_flags)) return hipErrorInvalidValue;
+  return edge_mode ? launch_flag_small_t<true>(a, robot_type, n_links, s) : launch_flag_small_t<false>(a, robot_type, n_links, s);
 }
 int launch_avoid(const EvalArgs& a, int robot_type, int n_links, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);

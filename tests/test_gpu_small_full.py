@@ -160,3 +160,34 @@ def test_flag_calls_of_a_few_states_equal_the_fused_path(monkeypatch, name, mode
     assert np.array_equal(got[True][clear], ref["flags"][clear])
     assert got[True][5] == 0
     assert 0 < got[True].sum() < 600 or name.startswith("c2k far")
+
+
+def test_edge_calls_of_a_few_steps_equal_the_fused_path(monkeypatch):
+    """OMPL's checkMotion (motion_planning.cpp:238,249: one edge per call): edge calls of up to 256 steps in all give
+    every step a block of two waves (flag_small_kernel, edge form); same first_invalid as the lane-per-step kernels
+    and as the oracle outside the band -- single edges, a few edges, ragged step counts, begin/end"""
+    model, params, boxes, s1, s2, nd64 = common.config4(n_edges=400)
+    sp = O.Space(params, model.n_joint)
+    nd_var = np.array([max(1, min(60, sp.valid_segment_count(s1[:, e], s2[:, e]))) for e in range(400)], np.int32)
+    g_ok, g_first, g_band = O.check_motion_batch(model, boxes, params, s1, s2, nd_var)
+    got = {}
+    for small in (True, False):
+        if not small:
+            monkeypatch.setenv("MVK_NO_SMALL_FULL", "1")
+        eng = mp.Engine(model, boxes, params)
+        ok, first = [], []
+        for e in range(200):                                   # one edge per call
+            o, f = eng.check_motion_batch(s1[:, e:e + 1], s2[:, e:e + 1], nd_var[e:e + 1])
+            ok.append(o); first.append(f)
+        for a in range(200, 400, 4):                           # four edges per call (<= 240 steps), uniform and ragged
+            o, f = eng.check_motion_batch(s1[:, a:a + 4], s2[:, a:a + 4], nd_var[a:a + 4])
+            ok.append(o); first.append(f)
+        eng.check_motion_batch_begin(s1[:, :3], s2[:, :3], 41)
+        o41, f41 = eng.check_motion_batch_end()
+        got[small] = (np.concatenate(ok), np.concatenate(first), o41, f41)
+        eng.close()
+    for a, b in zip(got[True], got[False]):
+        assert np.array_equal(a, b)
+    clear = ~g_band.astype(bool)
+    assert np.array_equal(got[True][0][clear], g_ok[clear]) and np.array_equal(got[True][1][clear], g_first[clear])
+    assert 0 < got[True][0].sum() < 400
