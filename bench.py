@@ -236,8 +236,12 @@ def workload_leg(name, n, dev, steps=10, warmup=2):
 
     import common
     import motion_planning_amd as mp
-    w = make_workload(name, n)
-    sweep = name == "c5"
+    statics_only = name == "c5_statics"   # the mode-0 sweep of scripts/state_validation_l4.py:46-68 (joints only, no collision)
+    w = make_workload("c5" if statics_only else name, n)
+    sweep = name in ("c5", "c5_statics")
+    if statics_only:
+        from motion_planning_amd import _abi as A
+        w.params = mp.default_params(w.model, A.MODE_ONLY_JOINTS, A.SE2)
     eng = mp.Engine(w.model, w.boxes, w.params, device=dev.index)
     d_soa = torch.from_numpy(w.soa).to(dev)
     mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
@@ -268,9 +272,11 @@ def workload_leg(name, n, dev, steps=10, warmup=2):
     eng.close()
     kind = "dragon" if w.model.has_gimbal else "hydrus"
     return {"workload": f"{name}: {kind.upper()} {w.model.n_rotor}-link, {n} samples, {len(w.boxes)} box obstacles"
-                        + (", states generated in-kernel (C-space sweep)" if sweep else ""),
+                        + (", states generated in-kernel (C-space sweep)" if sweep else "")
+                        + (", planning mode 0: joints only, stability verdict alone" if statics_only else ""),
             "ms_per_step": ms, "checks_per_s": n / ms * 1e3, "steps": steps, "valid_fraction": float(bits.mean()),
-            "roofline": roofline_of(name, w, n, screen_ms, exact_ms, ms, sweep)}
+            "roofline": None if statics_only else roofline_of(name, w, n, screen_ms, exact_ms, ms, sweep),
+            "kernel_ms": [screen_ms, exact_ms]}
 
 
 def fp32_variant(eng, w, d_soa, n, dev, steps=10):
@@ -554,7 +560,7 @@ def main():
         if not args.no_edges and world == 1:
             out["edge_checks"] = edge_checks(dev)
         if not args.no_legs and world == 1:
-            out["workloads"] = {k: workload_leg(k, n, dev) for k in ("c2", "c3", "c5") if k != args.workload}
+            out["workloads"] = {k: workload_leg(k, n, dev) for k in ("c2", "c3", "c5", "c5_statics") if k != args.workload}
         if not args.no_distance and world == 1 and not sweep:
             out["distance_path"] = distance_path(eng, w, d_soa, dev)
         if not args.no_distance and world == 1 and not sweep:
