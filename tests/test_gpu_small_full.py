@@ -191,3 +191,41 @@ def test_edge_calls_of_a_few_steps_equal_the_fused_path(monkeypatch):
     clear = ~g_band.astype(bool)
     assert np.array_equal(got[True][0][clear], g_ok[clear]) and np.array_equal(got[True][1][clear], g_first[clear])
     assert 0 < got[True][0].sum() < 400
+
+
+def test_mixed_small_calls_share_the_done_word_across_the_sequence_wrap():
+    """every polled call of a context (flag, full path, avoidance rows, edges; block-per-state kernels and the fused
+    kernel alike) takes the next 16-bit sequence number and the same pinned done word, and the edge tags pack that
+    number: 70 000 calls of all kinds in turn, across the wrap of the number, each checked against answers computed
+    beforehand in large calls"""
+    w = common.config2(n=2048)
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    big = eng.is_valid_batch(w.soa, w.layout, want=("flags", "min_dist", "margin", "band"))
+    av = eng.collision_avoidance_batch(w.soa[:, :64], w.layout)
+    model, params, boxes, s1, s2, nd = common.config4(n_edges=600)
+    eng_e = mp.Engine(model, boxes, params)
+    ok_all, first_all = eng_e.check_motion_batch(s1, s2, 41)       # one large call (two launches)
+    rng = np.random.default_rng(11)
+    for it in range(70000):
+        i = int(rng.integers(0, 2000))
+        kind = it % 7
+        e = i % 590
+        ok, first = eng_e.check_motion_batch(s1[:, e:e + 1], s2[:, e:e + 1], 41)    # OMPL checkMotion (its own context: numbers and tags)
+        assert ok[0] == ok_all[e] and first[0] == first_all[e], it
+        if kind < 4:        # OMPL isValid
+            assert eng.is_valid_batch(w.soa[:, i:i + 1], w.layout)["flags"][0] == big["flags"][i], it
+            if kind == 1 and it % 49 == 1:   # the fused kernel (more than 256 steps) on the same tags
+                ok, first = eng_e.check_motion_batch(s1[:, e:e + 9], s2[:, e:e + 9], 41)
+                assert np.array_equal(ok, ok_all[e:e + 9]) and np.array_equal(first, first_all[e:e + 9]), it
+        elif kind == 4:
+            got = eng.is_valid_batch(w.soa[:, i:i + 3], w.layout, want=("flags", "min_dist"))
+            assert np.array_equal(got["min_dist"], big["min_dist"][i:i + 3]) and np.array_equal(got["flags"], big["flags"][i:i + 3]), it
+        elif kind == 5 and it % 35 == 5:
+            j = i % 60
+            got = eng.collision_avoidance_batch(w.soa[:, j:j + 2], w.layout)
+            assert np.array_equal(got["dist"], av["dist"][:, j:j + 2]) and np.array_equal(got["box"], av["box"][:, j:j + 2]), it
+        else:
+            n = 300 + i % 50    # fused_kernel, state form
+            assert np.array_equal(eng.is_valid_batch(w.soa[:, :n], w.layout)["flags"], big["flags"][:n]), it
+    eng.close()
+    eng_e.close()
