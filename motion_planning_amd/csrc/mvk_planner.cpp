@@ -67,13 +67,14 @@ struct Tree {
   std::vector<double> states;  // row-major [n][dim]
   std::vector<int> parent;
   std::vector<std::vector<double>> col;  // the same states column-wise, for the vectorised nearest search
+  std::vector<std::vector<float>> colf;  // ... and in fp32, for its first pass
   int size() const { return static_cast<int>(parent.size()); }
   const double* at(int i) const { return states.data() + static_cast<size_t>(i) * dim; }
   int add(const double* s, int par) {
     states.insert(states.end(), s, s + dim);
     parent.push_back(par);
-    if (col.empty()) col.resize(dim);
-    for (int c = 0; c < dim; ++c) col[c].push_back(s[c]);
+    if (col.empty()) { col.resize(dim); colf.resize(dim); }
+    for (int c = 0; c < dim; ++c) { col[c].push_back(s[c]); colf[c].push_back(static_cast<float>(s[c])); }
     return size() - 1;
   }
 };
@@ -127,14 +128,14 @@ class Workers {
     }
   }
   Workers() {
-    // threads taking part, the caller included: half the CPUs this process may use (OMP_NUM_THREADS when
+    // threads taking part, the caller included: three quarters of the CPUs this process may use (OMP_NUM_THREADS when
     // set: a container's share of a bigger machine), at most 16; MVK_PLAN_THREADS overrides
     unsigned hw = std::thread::hardware_concurrency();
     if (const char* e = std::getenv("OMP_NUM_THREADS")) {
       const int v = std::atoi(e);
       if (v >= 1 && static_cast<unsigned>(v) < hw) hw = static_cast<unsigned>(v);
     }
-    int n = hw > 2 ? static_cast<int>(hw > 32 ? 16 : hw / 2) - 1 : 0;
+    int n = hw > 2 ? static_cast<int>(hw > 21 ? 16 : (3 * hw) / 4) - 1 : 0;
     if (const char* e = std::getenv("MVK_PLAN_THREADS")) {
       const int want = std::atoi(e);
       if (want >= 1 && want <= 64) n = want - 1;
@@ -228,6 +229,56 @@ inline __attribute__((always_inline)) int nearest_se2_fused(const mvk_params& p,
   return b0 + best;
 }
 
+// Two passes: the compound distance of every node in fp32 (eight nodes per AVX2 operation, and fp32 square roots
+// cost a quarter of the fp64 ones -- the two per node are most of the scan), then the fp64 distance of the few nodes
+// within kNearSlack of the fp32 minimum, with the first-index rule of the one-pass scan.  Coordinates are below 10 in
+// magnitude (positions, angles), so the fp32 value is within ~5e-6 of the fp64 one: the fp64 minimum is always among
+// the candidates and the result is the one-pass scan's.
+constexpr float kNearSlack = 2e-4f;
+template <int JT>
+inline __attribute__((always_inline)) int nearest_se2_two_pass(const mvk_params& p, const Tree& t, int b0, const double* s, float* __restrict__ accf) {
+  const int n = t.size() - b0;
+  const float* __restrict__ fx = t.colf[0].data() + b0;
+  const float* __restrict__ fy = t.colf[1].data() + b0;
+  const float* __restrict__ fw = t.colf[2].data() + b0;
+  const float* __restrict__ fj[JT > 0 ? JT : 1];
+  float qjf[JT > 0 ? JT : 1];
+  for (int j = 0; j < JT; ++j) { fj[j] = t.colf[3 + j].data() + b0; qjf[j] = static_cast<float>(s[3 + j]); }
+  const float qxf = static_cast<float>(s[0]), qyf = static_cast<float>(s[1]), qwf = static_cast<float>(s[2]);
+  const float wf = static_cast<float>(p.joint_subspace_weight), pif = static_cast<float>(kPi);
+#pragma clang loop vectorize(enable) interleave(enable)
+  for (int i = 0; i < n; ++i) {
+    float sj = 0.0f;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) { const float d = fj[j][i] - qjf[j]; sj += d * d; }
+    const float dx = fx[i] - qxf, dy = fy[i] - qyf;
+    float g = std::fabs(fw[i] - qwf);
+    g = g > pif ? 2.0f * pif - g : g;
+    accf[i] = (std::sqrt(dx * dx + dy * dy) + 0.5f * g) + wf * std::sqrt(sj);
+  }
+  float bf = INFINITY;
+  for (int i = 0; i < n; ++i) bf = accf[i] < bf ? accf[i] : bf;
+  const float thr = bf + kNearSlack + 1e-5f * bf;
+  // the candidates in fp64, exactly as nearest_se2_fused computes a node
+  const double qx = s[0], qy = s[1], qw = s[2], w = p.joint_subspace_weight;
+  double bd = INFINITY;
+  int best = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!(accf[i] <= thr)) continue;
+    double sj = 0.0;
+    for (int j = 0; j < JT; ++j) { const double d = t.col[3 + j][b0 + i] - s[3 + j]; sj += d * d; }
+    const double dx = t.col[0][b0 + i] - qx, dy = t.col[1][b0 + i] - qy;
+    double g = std::fabs(t.col[2][b0 + i] - qw);
+    g = g > kPi ? 2.0 * kPi - g : g;
+    const double d = (std::sqrt(dx * dx + dy * dy) + 0.5 * g) + w * std::sqrt(sj);
+    if (d < bd) { bd = d; best = i; }
+  }
+  return b0 + best;
+}
+__attribute__((target("avx2,fma"))) int nearest_se2_avx2_two_pass(const mvk_params& p, int J, const Tree& t, int b0, const double* s, float* accf) {
+  return J == 3 ? nearest_se2_two_pass<3>(p, t, b0, s, accf) : J == 5 ? nearest_se2_two_pass<5>(p, t, b0, s, accf) : nearest_se2_two_pass<7>(p, t, b0, s, accf);
+}
+
 // the same loop compiled for AVX2 + FMA (picked at run time) and for the baseline ISA
 __attribute__((target("avx2,fma"))) int nearest_se2_avx2(const mvk_params& p, int J, const Tree& t, int b0, const double* s, double* acc) {
   return J == 3 ? nearest_se2_fused<3>(p, t, b0, s, acc) : J == 5 ? nearest_se2_fused<5>(p, t, b0, s, acc) : nearest_se2_fused<7>(p, t, b0, s, acc);
@@ -240,8 +291,10 @@ int nearest(const mvk_params& p, int J, const Tree& t, const double* s, double* 
   const int n = t.size();
   if (p.planning_mode == MVK_MODE_JOINTS_AND_BASE && p.motion_type == MVK_SE2 && (J == 3 || J == 5 || J == 7)) {
     static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    static const bool one_pass = std::getenv("MVK_PLAN_ONE_PASS") != nullptr;  // diagnostics: the fp64 scan alone
     if (static_cast<int>(scratch.size()) < n) scratch.resize(static_cast<size_t>(n) + 256);
-    const int best = avx2 ? nearest_se2_avx2(p, J, t, b0, s, scratch.data()) : nearest_se2_base(p, J, t, b0, s, scratch.data());
+    const int best = (avx2 && !one_pass) ? nearest_se2_avx2_two_pass(p, J, t, b0, s, reinterpret_cast<float*>(scratch.data()))
+                     : avx2 ? nearest_se2_avx2(p, J, t, b0, s, scratch.data()) : nearest_se2_base(p, J, t, b0, s, scratch.data());
     *dist_out = mvk_space_distance(&p, J, t.at(best), s);
     return best;
   }
@@ -390,8 +443,15 @@ extern "C" int mvk_plan_rrt_connect_cb(const mvk_params* params, int J, const mv
       const int i = nearest(p, J, t, q + static_cast<size_t>(k) * dim, &d, scratch, b0);
       if (!merge || d < dst[k]) { idx[k] = i; dst[k] = d; }
     };
-    if (wide) Workers::get().parallel_for(n, job);
-    else for (int k = 0; k < n; ++k) job(k);
+    if (wide) {
+      // a ticket per query is a contended compare-exchange per ~0.2 us of work: hand the queries out in chunks
+      const int chunk = std::max(1, std::atoi(std::getenv("MVK_PLAN_CHUNK") ? std::getenv("MVK_PLAN_CHUNK") : "16"));
+      Workers::get().parallel_for((n + chunk - 1) / chunk, [&](int c) {
+        for (int k = c * chunk; k < std::min(n, (c + 1) * chunk); ++k) job(k);
+      });
+    } else {
+      for (int k = 0; k < n; ++k) job(k);
+    }
   };
   // the edge check in two halves, so that host work can run while the GPU checks (a checker
   // without the split interface does all its work in the second half)
