@@ -118,7 +118,9 @@ struct mvk_ctx {
   PinBuf pin_ctl;
   Buf first_tag;
   uint32_t fused_seq = 0;
+  int fused_max_blocks = kFusedMaxBlocks;  // blocks of kBlock lanes up to which a host call takes one fused launch
   bool fused_enabled = true;
+  bool split_enabled = true;       // edge batches of the fused path: two lanes per step (MVK_NO_SPLIT=1: one)
   Buf small_done;                  // distance_small_kernel: blocks finished, over all polled calls (never reset)
   uint32_t small_total = 0;        // ... and the count the last polled call ends on
   bool tag_clear_needed = false;   // the call sequence number has wrapped since first_tag was last cleared
@@ -547,7 +549,7 @@ int wait_last_call(mvk_ctx* c) {
 // eligible: flag path in fp64, at most kFusedMaxBlocks blocks of lanes (all resident at once)
 bool fused_eligible(const mvk_ctx* c, uint64_t lanes) {
   return c->fused_enabled && c->flag_precision == MVK_PRECISION_F64 && lanes > 0 &&
-         lanes <= static_cast<uint64_t>(kFusedMaxBlocks) * kBlock;
+         lanes <= static_cast<uint64_t>(c->fused_max_blocks) * kBlock;
 }
 // sequence number of a call that reports through the pinned done word (16 bits: first_tag packs it)
 uint32_t next_seq(mvk_ctx* c) {
@@ -809,6 +811,8 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
   if (const char* off = std::getenv("MVK_NO_SMALL_FULL")) c->small_full_enabled = off[0] != '1';  // diagnostics, tests
   if (const char* v = std::getenv("MVK_SMALL_FULL_MAX")) if (std::atoll(v) > 0) c->small_full_max = c->small_avoid_max = static_cast<uint64_t>(std::atoll(v));  // diagnostics
   if (const char* v = std::getenv("MVK_FLAG_SMALL_MAX")) if (std::atoll(v) > 0 && std::atoll(v) <= 1024) c->flag_small_max = static_cast<uint64_t>(std::atoll(v));  // diagnostics
+  if (const char* v = std::getenv("MVK_FUSED_MAX_BLOCKS")) if (std::atoi(v) > 0 && std::atoi(v) <= kFusedHardMax) c->fused_max_blocks = std::atoi(v);  // diagnostics
+  if (const char* off = std::getenv("MVK_NO_SPLIT")) c->split_enabled = off[0] != '1';  // diagnostics
   if (const char* off = std::getenv("MVK_NO_FUSED")) c->fused_enabled = off[0] != '1';  // diagnostics: always two launches
   return c;
 }
@@ -1467,6 +1471,7 @@ int run_edges_dev(mvk_ctx* c, const double* d_s1, const double* d_s2, size_t n_e
   if (int rc = enter_stream(c, s)) return rc;
   if (fused_host_first) {  // one launch; the arrays are pinned host memory the kernel reads and writes directly
     if (int rc = fused_arm(c, a, s, n_edges)) return rc;
+    if (c->split_enabled) a.fused = 2;  // fused_split_kernel: walk 1 and the collision screen of a step in two waves
     a.host_first = fused_host_first;
     a.first_invalid = nullptr;
     const int ef = launch_eval(a, c->model.robot_type, c->model.n_rotor, true, s, c->profiling ? c->ev : nullptr);
@@ -1653,6 +1658,8 @@ extern "C" int mvk_check_motion_batch_begin(mvk_ctx* c, const double* s1, const 
     c->edges_pending = true;
     return MVK_OK;
   }
+  // larger batches: two launches (the exact stage then has the whole chip, not only this call's blocks), one copy
+  // down, one synchronisation (a third kernel handing the verdicts to a polling host was 3-6 us slower: profiles/r02)
   return edges_submit_two_launches(c);
 }
 

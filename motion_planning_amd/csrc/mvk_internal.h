@@ -217,7 +217,8 @@ constexpr int kSmallGroup = 64;          // distance_small_kernel: lanes per sta
 constexpr uint64_t kSmallFullMax = 4096;  // states per call up to which the full path takes distance_small_kernel (profiles/small_full_time.py)
 constexpr uint64_t kSmallAvoidMax = 4096; // ... and the avoidance rows avoid_small_kernel
 constexpr uint64_t kFlagSmallMax = 256;   // flag path: states per host call up to which a state gets a block of its own (flag_small_kernel)
-constexpr int kFusedMaxBlocks = 96;     // fused_kernel: every block resident at once (fewer than CUs); measured gain up to ~80 blocks (profiles/latency.py)
+constexpr int kFusedHardMax = 96;       // most blocks a fused launch may have (MVK_FUSED_MAX_BLOCKS can raise the default up to here)
+constexpr int kFusedMaxBlocks = 28;     // fused kernels: blocks of kBlock lanes (every block resident at once); beyond ~7 k lanes two launches win (profiles/latency.py)
 
 
 // ---- the no-allocation flag path (mvk_is_valid_mask_noalloc_dev) -------------------------------------------

@@ -3178,6 +3178,61 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 // written to, pinned host memory directly; the last block to finish raises the done word the host polls.
 constexpr unsigned kFusedSpinLimit = 1u << 16;  // ~30 ms
 
+// the second half of a fused launch: grid barrier, exact stage, hand-over of the verdicts by the last block
+template <int ROBOT, int NL, bool EDGE>
+DEV void fused_tail(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                    const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf, unsigned char* lds, unsigned* sm_go) {
+  const bool second = A.do_coll && A.n_obs > 0;
+  if (second) {
+    // ---- grid barrier: every queue entry and record is in place before any block reads them ----
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(A.fused_bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0, go = 1u;
+      while (__hip_atomic_load(A.fused_bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        __builtin_amdgcn_s_sleep(16);  // ~0.4 us between polls: a few hundred pollers must not crowd the arrivals out of the L2 channel
+        if (++spins > kFusedSpinLimit) { go = 0u; break; }
+      }
+      (*sm_go) = go;
+    }
+    __syncthreads();
+    if (!(*sm_go)) {  // (never seen; the host repeats the call with two launches)
+      if (threadIdx.x == 0) {
+        *A.host_done = A.fused_seq | 0x80000000u;
+        __threadfence_system();
+      }
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    exact_body<ROBOT, NL, EDGE>(A, M, X, obs, obsf, lds);
+  }
+  // ---- completion: the last block to get here hands the verdicts to the host ----
+  __syncthreads();
+  // (the verdicts live in device memory -- flags, or first_tag -- until here: device-scope ordering is enough for
+  // every block but the last, which alone pays for a system-scope release)
+  if (threadIdx.x == 0)
+    (*sm_go) = __hip_atomic_fetch_add(A.fused_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!(*sm_go)) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (EDGE) {
+    for (uint64_t e = threadIdx.x; e < A.n_edges; e += kBlock) {
+      const unsigned v = __hip_atomic_load(A.first_tag + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int nd_e = A.nd ? (A.nd[e] < 1 ? 1 : A.nd[e]) : A.nd_uniform;
+      A.host_first[e] = (v >> 16) == (A.fused_seq & 0xFFFFu) ? static_cast<int>(0xFFFFu - (v & 0xFFFFu)) : nd_e + 1;
+    }
+  } else {  // flags: device buffer -> pinned host block, 16 bytes per lane and step (both padded to 64 bytes)
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(A.flags);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(A.host_flags);
+    for (uint64_t i = threadIdx.x; i < (A.n + 15) / 16; i += kBlock) dst[i] = src[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();  // one system-scope release for the whole block (cumulative over the barrier)
+    *A.host_done = A.fused_seq;
+  }
+}
+
 template <int ROBOT, int NL, bool EDGE>
 __global__ void __launch_bounds__(kBlock, (Shape<ROBOT, NL>::kScreenWaves))
 fused_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
@@ -3203,55 +3258,94 @@ fused_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   const bool in_range = gi < A.n;
   screen_body<ROBOT, NL, EDGE, false>(A, M, X, obsf, sm, L, gi, in_range ? gi : (A.n - 1), in_range, 0ull);
 
-  const bool second = A.do_coll && A.n_obs > 0;
-  if (second) {
-    // ---- grid barrier: every queue entry and record is in place before any block reads them ----
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(A.fused_bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned spins = 0, go = 1u;
-      while (__hip_atomic_load(A.fused_bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-        __builtin_amdgcn_s_sleep(16);  // ~0.4 us between polls: a few hundred pollers must not crowd the arrivals out of the L2 channel
-        if (++spins > kFusedSpinLimit) { go = 0u; break; }
+  fused_tail<ROBOT, NL, EDGE>(A, M, X, obs, obsf, lds, &sm_go);
+}
+
+
+// Edge batches of a planner iteration (a few hundred edges, ~20 k steps): at one wave per SIMD the lane of a step runs
+// walk 1 and then the collision screen, two chains of dependent work.  Here a block takes 128 steps and gives each
+// step TWO lanes in different waves: waves 2-3 run walk 1 (model_update), waves 0-1 the collision screen (own
+// cos/sin and root matrix, a few dozen instructions) and the hand-off to the exact stage.  In edge mode the halves need
+// not meet: either marks the step invalid in the edge's tag word.  A state that is unstable is still screened (its lane
+// would otherwise idle); marks are idempotent.  Twice the blocks of fused_kernel, all resident at once.
+template <int ROBOT, int NL>
+__global__ void __launch_bounds__(kBlock, 2)  // (at most one block per CU ever runs: registers over occupancy)
+fused_split_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                   const DevObs* __restrict__ obs, const DevObsF* __restrict__ obsf) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  constexpr int kHalf = kBlock / 2;
+  constexpr size_t kCs = sizeof(double) * 2 * NJ * kBlock, kRingB = sizeof(unsigned) * (kBlock / 64) * kRingWords * kRing,
+                   kResB = sizeof(unsigned) * kBlock, kThrB = sizeof(float) * S::kSeg * kSegPrimMax * 2;
+  constexpr size_t kScreenBytes = kCs + kRingB + kResB + kThrB, kExactBytes = ExactLds<ROBOT, NL>::kBytes;
+  __shared__ __align__(16) unsigned char lds[kScreenBytes > kExactBytes ? kScreenBytes : kExactBytes];
+  __shared__ unsigned sm_go;
+  Smem sm{(lds_double*)lds, nullptr};
+  const ScreenLds L{(lds_uint*)(lds + kCs) + (threadIdx.x >> 6) * (kRingWords * kRing), (lds_uint*)(lds + kCs + kRingB) + (threadIdx.x & ~63),
+                    (lds_float*)(lds + kCs + kRingB + kResB)};
+  if (threadIdx.x < S::kSeg * kSegPrimMax) {
+    float h2, m2;
+    screen_thresholds(A, X, threadIdx.x / kSegPrimMax, threadIdx.x % kSegPrimMax, A.f32_delta, h2, m2);
+    L.thr[2 * threadIdx.x] = h2;
+    L.thr[2 * threadIdx.x + 1] = m2;
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const bool model_half = tid >= kHalf;
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kHalf + static_cast<uint64_t>(tid & (kHalf - 1));
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+  // the counters the NEXT call on this ctx appends to (as screen_body)
+  if (!model_half && (gi < static_cast<uint64_t>(S::kSeg * kQueueShards) || (gi >= static_cast<uint64_t>(kDoneSlot) && gi <= static_cast<uint64_t>(kRefineSlot))))
+    A.queue_count_next[gi * kQueueCounterPitch] = 0u;
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, true, true>(A, li, st, edge, step);
+  if (model_half) {
+    StateOut o;
+    double Rw[9];
+    bool finite;
+    model_update<ROBOT, NL, false>(A, M, X, st, sm, li, o, Rw, finite, nullptr);
+    const bool ok = finite && (!A.do_stab || o.stable);
+    const bool band = !finite || (A.do_stab && fabs(o.margin) <= A.eps_margin);
+    if (in_range && !ok) mark_invalid_step(A, edge, step);
+    if (A.band && in_range && band) A.band[edge] = 1;
+  } else {
+    double Rw[9];
+    quat_to_mat(st[3], st[4], st[5], st[6], Rw);
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 7 + NJ; ++k) finite = finite && isfinite(st[k]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) finite = finite && isfinite(Rw[k]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      double sj, cj;
+      sincos_cw(st[7 + j], sj, cj);
+      sm.cs[(2 * j) * kBlock + tid] = cj;
+      sm.cs[(2 * j + 1) * kBlock + tid] = sj;
+    }
+    const bool live = finite && A.do_coll && A.n_obs > 0;
+    bool hit = false;
+    unsigned segmask = 0u;
+    if (__any(live)) collide_screen<ROBOT, NL>(A, M, X, obsf, st, Rw, sm, L, live, hit, segmask, nullptr);
+    if (in_range && hit) mark_invalid_step(A, edge, step);
+    const unsigned todo = (in_range && live && !hit) ? segmask : 0u;
+    if (__any(todo != 0u)) {
+      enqueue_undecided<ROBOT, NL, false>(A, gi, todo);
+      if (todo != 0u) {
+        double2* __restrict__ dst = reinterpret_cast<double2*>(A.queue_rec + gi * S::kRecPad);
+        dst[0] = make_double2(st[0], st[1]);
+        dst[1] = make_double2(st[2], st[3]);
+        dst[2] = make_double2(st[4], st[5]);
+        dst[3] = make_double2(st[6], 0.0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) dst[4 + j] = make_double2(sm.cs[(2 * j) * kBlock + tid], sm.cs[(2 * j + 1) * kBlock + tid]);
       }
-      sm_go = go;
     }
-    __syncthreads();
-    if (!sm_go) {  // (never seen; the host repeats the call with two launches)
-      if (threadIdx.x == 0) {
-        *A.host_done = A.fused_seq | 0x80000000u;
-        __threadfence_system();
-      }
-      return;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    exact_body<ROBOT, NL, EDGE>(A, M, X, obs, obsf, lds);
   }
-  // ---- completion: the last block to get here hands the verdicts to the host ----
-  __syncthreads();
-  // (the verdicts live in device memory -- flags, or first_tag -- until here: device-scope ordering is enough for
-  // every block but the last, which alone pays for a system-scope release)
-  if (threadIdx.x == 0)
-    sm_go = __hip_atomic_fetch_add(A.fused_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
-  __syncthreads();
-  if (!sm_go) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (EDGE) {
-    for (uint64_t e = threadIdx.x; e < A.n_edges; e += kBlock) {
-      const unsigned v = __hip_atomic_load(A.first_tag + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int nd_e = A.nd ? (A.nd[e] < 1 ? 1 : A.nd[e]) : A.nd_uniform;
-      A.host_first[e] = (v >> 16) == (A.fused_seq & 0xFFFFu) ? static_cast<int>(0xFFFFu - (v & 0xFFFFu)) : nd_e + 1;
-    }
-  } else {  // flags: device buffer -> pinned host block, 16 bytes per lane and step (both padded to 64 bytes)
-    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(A.flags);
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(A.host_flags);
-    for (uint64_t i = threadIdx.x; i < (A.n + 15) / 16; i += kBlock) dst[i] = src[i];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence_system();  // one system-scope release for the whole block (cumulative over the barrier)
-    *A.host_done = A.fused_seq;
-  }
+  fused_tail<ROBOT, NL, true>(A, M, X, obs, obsf, lds, &sm_go);
 }
 
 // Full path = two launches on one stream: the statics want registers and have no gathers, the distance
@@ -4546,8 +4640,11 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s, hipEvent_t* e
     return hipGetLastError();
   }
   if (a.fused) {
-    if (blocks > static_cast<uint64_t>(kFusedMaxBlocks)) return hipErrorInvalidValue;
-    if (edge_mode) hipLaunchKernelGGL((fused_kernel<ROBOT, NL, true>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
+    if (blocks > static_cast<uint64_t>(kFusedHardMax)) return hipErrorInvalidValue;
+    if (edge_mode && a.fused == 2) {
+      const dim3 g2(static_cast<unsigned>((a.n + kBlock / 2 - 1) / (kBlock / 2)));
+      hipLaunchKernelGGL((fused_split_kernel<ROBOT, NL>), g2, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
+    } else if (edge_mode) hipLaunchKernelGGL((fused_kernel<ROBOT, NL, true>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
     else hipLaunchKernelGGL((fused_kernel<ROBOT, NL, false>), g, b, 0, s, a, a.model, a.extras, a.obs, a.obsf);
     if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
     return hipGetLastError();
