@@ -669,8 +669,7 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
       a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
       a.fused_seq = poll_seq;
       a.fused_done = static_cast<uint32_t*>(c->small_done.p);
-      c->small_total += static_cast<uint32_t>(stat_blocks);
-      a.small_target = c->small_total;
+      a.small_target = c->small_total + static_cast<uint32_t>(stat_blocks);  // (committed once the launch has succeeded)
     }
     if (int rc = c->partial.reserve(stat_blocks * sizeof(StatsPartial))) return rc;
     a.stats_partial = c->partial.p;
@@ -689,6 +688,7 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
   const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s, c->profiling ? c->ev : nullptr);
   c->timed = c->profiling;
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+  if (poll_seq) c->small_total = a.small_target;
   c->stats_valid = a.full != 0;
   return leave_stream(c, s);
 }
@@ -1098,12 +1098,12 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
       a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
       a.fused_seq = next_seq(c);
       a.fused_done = static_cast<uint32_t*>(c->small_done.p);
-      c->small_total += static_cast<uint32_t>(n);
-      a.small_target = c->small_total;
+      a.small_target = c->small_total + static_cast<uint32_t>(n);
       c->stats_valid = false;
       if (c->profiling) (void)hipEventRecord(c->ev[0], s);
       const int e = launch_flag_small(a, c->model.robot_type, c->model.n_rotor, false, s);
       if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+      c->small_total = a.small_target;
       if (c->profiling) { (void)hipEventRecord(c->ev[1], s); (void)hipEventRecord(c->ev[2], s); }
       c->timed = c->profiling;
       if (int rc = leave_stream(c, s)) return rc;
@@ -1333,13 +1333,13 @@ int run_avoid_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layo
     a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
     a.fused_seq = poll_seq;
     a.fused_done = static_cast<uint32_t*>(c->small_done.p);
-    c->small_total += static_cast<uint32_t>((n + (kBlock / 64) - 1) / (kBlock / 64));
-    a.small_target = c->small_total;
+    a.small_target = c->small_total + static_cast<uint32_t>((n + (kBlock / 64) - 1) / (kBlock / 64));
   }
   c->stats_valid = false;
   if (int rc = enter_stream(c, static_cast<hipStream_t>(stream))) return rc;
   const int e = launch_avoid(a, c->model.robot_type, c->model.n_rotor, stream);
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "avoidance kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+  if (poll_seq) c->small_total = a.small_target;
   return leave_stream(c, static_cast<hipStream_t>(stream));
 }
 }  // namespace
@@ -1627,11 +1627,11 @@ extern "C" int mvk_check_motion_batch_begin(mvk_ctx* c, const double* s1, const 
     }
     a.host_first = static_cast<int32_t*>(c->pin_down.p);
     a.fused_done = static_cast<uint32_t*>(c->small_done.p);
-    c->small_total += static_cast<uint32_t>(total);
-    a.small_target = c->small_total;
+    a.small_target = c->small_total + static_cast<uint32_t>(total);
     if (c->profiling) (void)hipEventRecord(c->ev[0], s);
     const int e = launch_flag_small(a, c->model.robot_type, c->model.n_rotor, true, s);
     if (e != hipSuccess) return fail(MVK_ERR_HIP, "edge kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
+    c->small_total = a.small_target;
     if (c->profiling) { (void)hipEventRecord(c->ev[1], s); (void)hipEventRecord(c->ev[2], s); }
     c->timed = c->profiling;
     if (int rc = leave_stream(c, s)) return rc;
