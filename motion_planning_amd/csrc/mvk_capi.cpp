@@ -68,7 +68,7 @@ struct PinBuf {  // grow-only pinned host buffer (async copies from pageable mem
     p = nullptr;
     cap = 0;
     size_t want = std::max<size_t>(bytes + bytes / 4 + 4096, size_t{1} << 18);  // small calls never re-pin
-    HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&p, want, hipHostMallocCoherent));  // fine-grained: kernels write answers and done words here that the host reads while they run
     cap = want;
     return MVK_OK;
   }
