@@ -663,7 +663,8 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
     // small batches with a collision stage: distance_small_kernel, a group of lanes per state (and a partial per
     // block of kBlock / kSmallGroup states)
     a.small_full = (a.do_coll && a.n_obs > 0 && !d_mask && n <= c->small_full_max && c->small_full_enabled) ? 1 : 0;
-    const uint64_t stat_blocks = a.small_full ? (n + (kBlock / kSmallGroup) - 1) / (kBlock / kSmallGroup) : blocks;
+    if (a.small_full && n <= kFullOneLaunchMax) a.small_full = 2;  // walk 1 in the same launch, two states per block
+    const uint64_t stat_blocks = a.small_full == 2 ? (n + 1) / 2 : a.small_full ? (n + (kBlock / kSmallGroup) - 1) / (kBlock / kSmallGroup) : blocks;
     if (poll_seq) {  // eval_host: outputs in pinned memory, completion through the pinned done word
       if (!a.small_full) return fail(MVK_ERR_INVALID_ARG, "internal: polled completion asked of a call that does not take distance_small_kernel");
       a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
@@ -675,7 +676,7 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
     a.stats_partial = c->partial.p;
     c->last_blocks = stat_blocks;
     c->last_n = n;
-    if (a.do_coll && a.n_obs > 0) {  // the distance kernel follows: hand-off rows for every launched lane
+    if (a.do_coll && a.n_obs > 0 && a.small_full != 2) {  // the distance kernel follows: hand-off rows for every launched lane
       const uint64_t rec_ld = blocks * kBlock;
       if (int rc = c->full_rec.reserve((2 * static_cast<uint64_t>(c->model.n_joint) + 5) * rec_ld * sizeof(double))) return rc;
       a.full_rec = static_cast<double*>(c->full_rec.p);

@@ -180,7 +180,7 @@ struct EvalArgs {
   uint64_t full_rec_ld;
   // full path, small batches (distance_small_kernel): kSmallGroup lanes per state; the second, wider distance grid
   // serves the primitives the first one cannot answer before the sweep over all boxes does
-  int32_t small_full;
+  int32_t small_full;     // 1: model_kernel + distance_small_kernel; 2: full_small_kernel (one launch, two states per block)
   uint32_t small_target;  // host_done set: the block that brings *fused_done to this count raises the done word
   GridDev dgrid2;
   double dgrid2_radius;
@@ -215,6 +215,7 @@ constexpr int kQueueShards = 8;         // queues per segment (MVK_MAX_SEG * kQu
 constexpr int kQueueCounterPitch = 64;  // uint32 words between two counters: one 256-byte line each
 constexpr int kSmallGroup = 64;          // distance_small_kernel: lanes per state (>= MVK_MAX_PRIM)
 constexpr uint64_t kSmallFullMax = 4096;  // states per call up to which the full path takes distance_small_kernel (profiles/small_full_time.py)
+constexpr uint64_t kFullOneLaunchMax = 256;  // ... and up to which walk 1 joins it in the same launch (full_small_kernel)
 constexpr uint64_t kSmallAvoidMax = 4096; // ... and the avoidance rows avoid_small_kernel
 constexpr uint64_t kFlagSmallMax = 256;   // flag path: states per host call up to which a state gets a block of its own (flag_small_kernel)
 constexpr int kFusedHardMax = 96;       // most blocks a fused launch may have (MVK_FUSED_MAX_BLOCKS can raise the default up to here)

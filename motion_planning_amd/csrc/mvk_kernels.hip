@@ -3694,34 +3694,13 @@ DEV double exact_cp_wave_ab(lds_double* item, lds_u64* res, lds_double* s2s, lds
 // Candidates: the distance grid's cell list of the primitive's centre (complete within dgrid_radius); a primitive the
 // list cannot answer (rb + max(minimum, 0) beyond the radius) goes on to the wider second grid, then to all boxes.
 static_assert(kSmallGroup >= MVK_MAX_PRIM && kBlock % kSmallGroup == 0 && kSmallGroup <= 64 && 64 % kSmallGroup == 0, "one group per state inside a wave");
+// the wave's work on one state: the minimum signed distance over its primitives and the boxes (`sub` = lane within the
+// state's group, R / p = the root frame, cs = the joints' cos/sin); returned to every lane of the group
 template <int ROBOT, int NL>
-__global__ void __launch_bounds__(kBlock)
-distance_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
-                      const DevObs* __restrict__ obs) {
+DEV double distance_small_body(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                               const DevObs* __restrict__ obs, bool in_range, bool finite, int sub, double R[9], double p[3],
+                               const double* cs, lds_double* ex_item, lds_u64* ex_res) {
   using S = Shape<ROBOT, NL>;
-  constexpr int NJ = S::kJoint;
-  __shared__ double sm_ex_item[(kBlock / 64) * kExactBatch * kExactItemAB];
-  __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kExactBatch];
-  const int tid = threadIdx.x, sub = tid & (kSmallGroup - 1);
-  lds_double* ex_item = (lds_double*)sm_ex_item + (tid >> 6) * kExactBatch * kExactItemAB;
-  lds_u64* ex_res = (lds_u64*)sm_ex_res + (tid >> 6) * kExactBatch;
-  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * (kBlock / kSmallGroup) + static_cast<uint64_t>(tid / kSmallGroup);
-  const bool in_range = gi < A.n;
-  const uint64_t li = in_range ? gi : (A.n - 1);
-
-  double st[7 + NJ];
-  uint64_t edge;
-  int step;
-  fetch_state<NJ, false, false>(A, li, st, edge, step);
-  // the joints' cos/sin rows of the model kernel, all loads in flight at once
-  double cs[2 * NJ];
-#pragma unroll
-  for (int r = 0; r < 2 * NJ; ++r) cs[r] = A.full_rec[static_cast<uint64_t>(r) * A.full_rec_ld + li];
-  double R[9], p[3] = {st[0], st[1], st[2]};
-  quat_to_mat(st[3], st[4], st[5], st[6], R);
-  const double* __restrict__ sc = A.full_rec + static_cast<uint64_t>(2 * NJ) * A.full_rec_ld;
-  const bool finite = sc[static_cast<uint64_t>(kFullRecFinite) * A.full_rec_ld + li] != 0.0;
-
   const int P = M->n_prim;
   const int K = kSmallGroup / P;  // >= 1 (P <= MVK_MAX_PRIM)
   const bool active = in_range && finite && sub < P * K;
@@ -3810,6 +3789,38 @@ distance_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const D
   }
   if (__any(todo)) scan(nullptr, todo ? A.n_obs : 0);
   const double mind = group_min(best);
+  return mind;
+}
+
+template <int ROBOT, int NL>
+__global__ void __launch_bounds__(kBlock)
+distance_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                      const DevObs* __restrict__ obs) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ double sm_ex_item[(kBlock / 64) * kExactBatch * kExactItemAB];
+  __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kExactBatch];
+  const int tid = threadIdx.x, sub = tid & (kSmallGroup - 1);
+  lds_double* ex_item = (lds_double*)sm_ex_item + (tid >> 6) * kExactBatch * kExactItemAB;
+  lds_u64* ex_res = (lds_u64*)sm_ex_res + (tid >> 6) * kExactBatch;
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * (kBlock / kSmallGroup) + static_cast<uint64_t>(tid / kSmallGroup);
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, false, false>(A, li, st, edge, step);
+  // the joints' cos/sin rows of the model kernel, all loads in flight at once
+  double cs[2 * NJ];
+#pragma unroll
+  for (int r = 0; r < 2 * NJ; ++r) cs[r] = A.full_rec[static_cast<uint64_t>(r) * A.full_rec_ld + li];
+  double R[9], p[3] = {st[0], st[1], st[2]};
+  quat_to_mat(st[3], st[4], st[5], st[6], R);
+  const double* __restrict__ sc = A.full_rec + static_cast<uint64_t>(2 * NJ) * A.full_rec_ld;
+  const bool finite = sc[static_cast<uint64_t>(kFullRecFinite) * A.full_rec_ld + li] != 0.0;
+
+  const double mind = distance_small_body<ROBOT, NL>(A, M, X, obs, in_range, finite, sub, R, p, cs, ex_item, ex_res);
 
   const bool report = in_range && sub == 0;
   const double margin = sc[static_cast<uint64_t>(kFullRecMargin) * A.full_rec_ld + li];
@@ -3818,6 +3829,82 @@ distance_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const D
               mind, margin >= 0.0);
   // a host caller polling a pinned word instead of synchronising the stream (outputs in pinned memory): every block
   // releases its writes to the system, the last one to arrive raises the word
+  if (A.host_done) {
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence_system();
+      const unsigned before = atomicAdd(A.fused_done, 1u);
+      if (before + 1u == A.small_target) {
+        __threadfence_system();
+        *A.host_done = A.fused_seq;
+      }
+    }
+  }
+}
+
+// The full path of a few states in ONE launch (mvk_is_valid, clearance queries): a block takes two states and gives
+// each a wave for the distance stage (as above, cos/sin taken here) and a wave for walk 1 in full (model_update with
+// its detail outputs, every lane the same state); the halves meet in LDS for verdict, band and statistics.  Saves the
+// model kernel's launch and the hand-off rows.
+template <int ROBOT, int NL>
+__global__ void __launch_bounds__(kBlock)
+full_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
+                  const DevObs* __restrict__ obs) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ double sm_cs[2 * NJ * kBlock];
+  __shared__ double sm_ex_item[(kBlock / 64) * kExactBatch * kExactItemAB];
+  __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kExactBatch];
+  __shared__ double sm_model[2][6];  // per state of the block: margin, lam_min, lam_max, rp margin, finite
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, slot = wv & 1;
+  const bool model_wave = wv >= 2;
+  lds_double* ex_item = (lds_double*)sm_ex_item + wv * kExactBatch * kExactItemAB;
+  lds_u64* ex_res = (lds_u64*)sm_ex_res + wv * kExactBatch;
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * 2 + static_cast<uint64_t>(slot);
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, false, true>(A, li, st, edge, step);
+  double mind = INFINITY;
+  if (model_wave) {
+    Smem sm{(lds_double*)sm_cs, nullptr};
+    StateOut o;
+    double thrust[NL];
+    double Rw[9];
+    bool finite;
+    model_update<ROBOT, NL, true>(A, M, X, st, sm, li, o, Rw, finite, thrust);
+    if (lane == 0) {
+      if (in_range) {
+        if (A.fc_t_min) A.fc_t_min[gi] = o.fc_t_min;
+        if (A.fc_rp_min) A.fc_rp_min[gi] = o.fc_rp_min;
+        if (A.rp_margin) A.rp_margin[gi] = o.rp_margin;
+        if (A.thrust) {
+#pragma unroll
+          for (int i = 0; i < NL; ++i) A.thrust[i * A.ld + gi] = thrust[i];
+        }
+      }
+      sm_model[slot][0] = o.margin; sm_model[slot][1] = o.lam_min; sm_model[slot][2] = o.lam_max;
+      sm_model[slot][3] = o.rp_margin; sm_model[slot][4] = finite ? 1.0 : 0.0;
+    }
+  } else {
+    double R[9], p[3] = {st[0], st[1], st[2]};
+    quat_to_mat(st[3], st[4], st[5], st[6], R);
+    bool finite = true;  // as model_update decides it
+#pragma unroll
+    for (int k = 0; k < 7 + NJ; ++k) finite = finite && isfinite(st[k]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) finite = finite && isfinite(R[k]);
+    double cs[2 * NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) sincos_cw(st[7 + j], cs[2 * j + 1], cs[2 * j]);
+    mind = distance_small_body<ROBOT, NL>(A, M, X, obs, in_range, finite, lane, R, p, cs, ex_item, ex_res);
+  }
+  __syncthreads();
+  const double margin = sm_model[slot][0];
+  const bool finite = sm_model[slot][4] != 0.0;
+  full_finish(A, gi, !model_wave && in_range && lane == 0, finite, margin, sm_model[slot][1], sm_model[slot][2], sm_model[slot][3], mind, margin >= 0.0);
   if (A.host_done) {
     __syncthreads();
     if (tid == 0) {
@@ -4627,6 +4714,12 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s, hipEvent_t* e
   if (blocks > 0x7fffffffULL || a.n > 0xffffffffULL) return hipErrorInvalidValue;  // 32-bit queue entries
   dim3 g(static_cast<unsigned>(blocks)), b(kBlock);
   if (ev) (void)hipEventRecord(ev[0], s);
+  if (a.full && !edge_mode && a.small_full == 2) {  // a few states: walk 1 and the distance stage in one launch, two states per block
+    const dim3 gs(static_cast<unsigned>((a.n + 1) / 2));
+    hipLaunchKernelGGL((full_small_kernel<ROBOT, NL>), gs, b, 0, s, a, a.model, a.extras, a.obs);
+    if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
+    return hipGetLastError();
+  }
   if (a.full && !edge_mode) {
     hipLaunchKernelGGL((model_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras);
     if (ev) (void)hipEventRecord(ev[1], s);

@@ -51,6 +51,6 @@ def test_model_kernel_has_no_scratch_and_distance_kernels_keep_two_waves():
 
 def test_latency_kernels_do_not_spill_vector_registers():
     k = _kernels()
-    for name in ("17flag_small_kernelI", "21distance_small_kernelI", "18avoid_small_kernelI"):
+    for name in ("17flag_small_kernelI", "21distance_small_kernelI", "17full_small_kernelI", "18avoid_small_kernelI", "18fused_split_kernelI"):
         for r in _pick(k, name):
             assert r["VGPRs Spill"] == 0, (name, r)
