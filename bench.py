@@ -125,7 +125,23 @@ def edge_checks(dev):
             "edges_per_s": E / ms * 1e3, "checks_per_s": E * nd / ms * 1e3, "valid_edge_fraction": float(ok.float().mean().item())}
 
 
-def distance_path(eng, w, d_soa, dev):
+def distance_roofline(workload, kernel, n, ms):
+    """VALU-issue roofline of a distance kernel, as roofline_of: executed wave instructions per launch (committed PMC
+    pass, scaled to n states) / the time measured here / 6.144e11 per s.  None when no PMC pass is committed."""
+    ent = pmc_traffic(workload + ".distance") or {}
+    k = ent.get(kernel)
+    if not k:
+        return None
+    insts = k["valu_insts_per_launch"] * n / k.get("states_per_launch", ent["states_per_launch"])
+    return {"bound": "valu_fp64", "kernel": kernel, "frac": insts / (ms * 1e-3) / 6.144e11,
+            "frac_definition": "executed VALU wave instructions per launch (PMC SQ_INSTS_VALU) / ms / 6.144e11 per s; ms here includes "
+                               "model_kernel (3-5 % of the call)" if kernel == "distance_kernel" else
+                               "executed VALU wave instructions per launch (PMC SQ_INSTS_VALU) / ms / 6.144e11 per s",
+            "valu_wave_insts_per_launch": insts, "valu_busy_pmc": k["valu_busy"], "wait_any_frac_pmc": k["wait_any_frac"],
+            "pmc_source": ent["source"]}
+
+
+def distance_path(eng, w, d_soa, dev, workload=None):
     """the same batch through the distance kernels: full path (flags + exact minimum distance + margins + batch
     statistics) and the collision-avoidance rows (8(f)-3) on the first 262 144 states"""
     import torch
@@ -156,9 +172,11 @@ def distance_path(eng, w, d_soa, dev):
     avoid_ms = timed(lambda: eng.collision_avoidance_batch_dev(da, w.layout, outs))
     return {"full_path": {"states": n, "ms": full_ms, "states_per_s": n / full_ms * 1e3,
                           "outputs": "flags, min_dist, margin per state + batch statistics",
-                          "min_dist": stats["min_dist"], "min_margin": stats["min_margin"], "valid": stats["valid_count"]},
+                          "min_dist": stats["min_dist"], "min_margin": stats["min_margin"], "valid": stats["valid_count"],
+                          "roofline": distance_roofline(workload, "distance_kernel", n, full_ms) if workload else None},
             "avoidance_rows": {"states": na, "ms": avoid_ms, "states_per_s": na / avoid_ms * 1e3,
-                               "outputs": "per primitive: distance, nearest box and points, constraint row, bound"}}
+                               "outputs": "per primitive: distance, nearest box and points, constraint row, bound",
+                               "roofline": distance_roofline(workload, "avoid_kernel", na, avoid_ms) if workload else None}}
 
 
 def single_calls(eng, w):
@@ -562,7 +580,7 @@ def main():
         if not args.no_legs and world == 1:
             out["workloads"] = {k: workload_leg(k, n, dev) for k in ("c2", "c3", "c5", "c5_statics") if k != args.workload}
         if not args.no_distance and world == 1 and not sweep:
-            out["distance_path"] = distance_path(eng, w, d_soa, dev)
+            out["distance_path"] = distance_path(eng, w, d_soa, dev, args.workload)
         if not args.no_distance and world == 1 and not sweep:
             out["single_calls"] = single_calls(eng, w)
         if not args.no_fp32 and world == 1 and not sweep:

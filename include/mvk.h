@@ -226,6 +226,13 @@ int mvk_scene_vertical_gap(double gap_x_width, double gap_y_width, double gap_he
  * counts[i] = number of ids for point i (may exceed cap; only cap are written). */
 int mvk_broadphase_query(const mvk_box* boxes, size_t n_boxes, double radius, const double* points /*[n][3]*/,
                          size_t n_points, int32_t* counts, int32_t* ids /*[n][cap]*/, int cap);
+/* The same for the far grid of the distance paths (the role of FCL's distance traversal of the broadphase tree under
+ * CollisionAvoidance::getConstraint, collision_avoidance.cpp:147-153: nearest objects first, at any distance): a cell
+ * lists every box whose distance to a point of the cell is within `reach` of the smallest such distance, so the boxes
+ * that can be nearest to a primitive of bounding radius <= reach centred there are all listed.  Covers the boxes'
+ * bound inflated by `margin`; counts[i] = -1 for a point outside it (the kernels then sweep all boxes). */
+int mvk_far_grid_query(const mvk_box* boxes, size_t n_boxes, double reach, double margin, const double* points /*[n][3]*/,
+                       size_t n_points, int32_t* counts, int32_t* ids /*[n][cap]*/, int cap);
 
 /* ---- context --------------------------------------------------------------- */
 /* Replaces MotionPlanning's ownership of robot_model_ptr_ + planning_scene_

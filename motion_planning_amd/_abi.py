@@ -125,6 +125,7 @@ PROTOTYPES = {
     "mvk_scene_horizontal_gap": (ip, [d, d, d, d, PB, ip]),
     "mvk_scene_vertical_gap": (ip, [d, d, d, ip, d, d, PB, ip]),
     "mvk_broadphase_query": (ip, [PB, sz, d, vp, sz, vp, vp, ip]),
+    "mvk_far_grid_query": (ip, [PB, sz, d, d, vp, sz, vp, vp, ip]),
     "mvk_create": (vp, [PM, PB, sz, PP, ip]),
     "mvk_destroy": (None, [vp]),
     "mvk_set_scene": (ip, [vp, PB, sz]),

@@ -103,7 +103,7 @@ struct mvk_ctx {
   DevExtras extras{};
   mvk_model* d_model = nullptr;
   DevExtras* d_extras = nullptr;
-  Buf obs, obsf, grid_start, grid_items, dgrid_start[2], dgrid_items[2];
+  Buf obs, obsf, grid_start, grid_items, dgrid_start[2], dgrid_items[2], fgrid_start, fgrid_items;
   // flag path hand-off between the screen and the exact stage (see EvalArgs).  Two alternating sets
   // of queue counters: call k appends to set k%2 and zeroes set (k+1)%2, so no memset sits between
   // launches.  Calls on one ctx must therefore be ordered with respect to each other (one stream at a time).
@@ -112,7 +112,7 @@ struct mvk_ctx {
   int flag_precision = MVK_PRECISION_F64;  // mvk_set_flag_precision
   float f32_delta_fk = 0.0f;
   float f32_bound_scale = 1.0f;
-  const uint32_t* last_refine_counter = nullptr;
+  const uint32_t* last_refine_counter = nullptr;  // device address of the last fp32-variant call's refine counter
   // small host batches in one launch (fused_kernel): a pinned control block holding the done word the kernel
   // raises, the 16-bit call sequence, the per-edge tag array, and what the last fused call still owes the caller
   PinBuf pin_ctl;
@@ -132,7 +132,7 @@ struct mvk_ctx {
   size_t edges_n = 0, edges_dld = 0, edges_blob_bytes = 0;
   uint64_t edges_total = 0;
   bool edges_have_nd = false;
-  int32_t edges_nu = 1;  // device address of the last fp32-variant call's refine counter
+  int32_t edges_nu = 1;
   uint64_t call_index = 0;
   int n_cu = 256;
   // mvk_check_motion_batch_begin / _end
@@ -144,6 +144,7 @@ struct mvk_ctx {
   GridDev grid{};
   GridDev dgrid[2] = {};  // distance grids: [0] full path, [1] avoidance rows (start == nullptr: not in use for this scene)
   double dgrid_radius[2] = {0.0, 0.0};
+  GridDev fgrid{};  // far grid: nearest-candidate lists without a radius (mvk_grid.cpp build_far_grid), behind the two above
   int n_obs = 0;
   float f32_delta = 0.0f;
   double f32_range = 0.0;
@@ -346,16 +347,17 @@ int boxes_to_obs(const mvk_box* boxes, size_t n, std::vector<DevObs>& host) {
 // radius = (largest primitive bounding radius + slack) of the centre, so whenever an upper bound <= slack of
 // the distance sought is known, the list holds every box that can realise the minimum and the sweep over all
 // boxes is not needed.  The slack is read off the scene: a percentile of the distance from a point of the
-// obstacles' bounding volume to the nearest box.  The full path bounds a state by its closest primitive and
-// takes the 60th percentile (short lists; a state needs the sweep only when the whole robot is farther than
-// that from every box); the avoidance rows need the nearest box of every primitive on its own and take the
-// 95th.  Measured on c2 / c2k / c3 / c5 (profiles/full_time.py with MVK_DISTANCE_GRID_PCT).  Scenes where the
-// lists would not be much shorter than the whole set keep the sweep (scalar loads at wave-uniform addresses).
+// obstacles' bounding volume to the nearest box.  Grid 0 takes the 25th percentile (short lists for the states close
+// to something, which is most of them), grid 1 the 95th: the full path asks grid 0 first and falls back to grid 1 for
+// the states it cannot answer, the avoidance rows (nearest box of every primitive on its own) use grid 1.  Measured on
+// c2 / c2k / c3 / c5 (profiles/pct_sweep.sh).  Scenes where the lists would not be much shorter than the whole set
+// keep the sweep (scalar loads at wave-uniform addresses).
 int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
   for (int g = 0; g < 2; ++g) {
     c->dgrid[g] = GridDev{};
     c->dgrid_radius[g] = 0.0;
   }
+  c->fgrid = GridDev{};
   const size_t n = host.size();
   if (n < 64) return MVK_OK;
   // diagnostics (profiles/full_time.py, tests): keep the sweep over all boxes for scenes set from now on
@@ -423,6 +425,33 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
     if (std::getenv("MVK_DISTANCE_GRID_TRACE"))
       std::fprintf(stderr, "mvk: distance grid %d: radius %.3f (slack %.3f), cell %.3f, %d x %d x %d cells, mean list %.1f of %zu boxes\n",
                    g, gh.radius, gh.radius - rb, gh.h, gh.n[0], gh.n[1], gh.n[2], mean_len, n);
+  }
+  // Behind them, for the primitives neither can answer (farther from every box than the second grid's slack: open
+  // space, the rim of the obstacles' volume): the far grid, whose lists are complete at any distance.  It replaces
+  // the sweep over all boxes inside the boxes' bound inflated by the robot's reach.
+  bool far_on = c->dgrid[0].start != nullptr || c->dgrid[1].start != nullptr;
+  if (const char* off = std::getenv("MVK_NO_FAR_GRID")) if (off[0] == '1') far_on = false;  // diagnostics, tests
+  if (far_on) {
+    double diag = 0.0;
+    for (int k = 0; k < 3; ++k) diag += (hi[k] - lo[k]) * (hi[k] - lo[k]);
+    const double margin = std::fmin(std::fmax(c->extras.reach, 0.5), 4.0);
+    const double pad = 8.0 * static_cast<double>(c->f32_delta) + 4e-6 * (std::sqrt(diag) + 2.0 * margin) + 1e-6;
+    GridHost gh;
+    if (build_far_grid(host.data(), n, rb, margin, pad, gh) == MVK_OK) {
+      if (int rc = c->fgrid_start.reserve(sizeof(uint32_t) * gh.start.size())) return rc;
+      if (int rc = c->fgrid_items.reserve(sizeof(uint16_t) * (gh.items.size() + kGridGroup))) return rc;
+      HIP_TRY(hipMemcpy(c->fgrid_start.p, gh.start.data(), sizeof(uint32_t) * gh.start.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(c->fgrid_items.p, gh.items.data(), sizeof(uint16_t) * gh.items.size(), hipMemcpyHostToDevice));
+      GridDev& d = c->fgrid;
+      for (int k = 0; k < 3; ++k) { d.origin[k] = gh.origin[k]; d.n[k] = gh.n[k]; }
+      d.inv_h = 1.0 / gh.h;
+      d.pad = 0;
+      d.start = static_cast<const uint32_t*>(c->fgrid_start.p);
+      d.items = static_cast<const uint16_t*>(c->fgrid_items.p);
+      if (std::getenv("MVK_DISTANCE_GRID_TRACE"))
+        std::fprintf(stderr, "mvk: far grid: margin %.2f, cell %.3f, %d x %d x %d cells, mean list %.1f of %zu boxes\n", margin, gh.h, gh.n[0],
+                     gh.n[1], gh.n[2], static_cast<double>(gh.items.size()) / static_cast<double>(gh.start.size() - 1), n);
+    }
   }
   return MVK_OK;
 }
@@ -515,6 +544,7 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
   a.dgrid_radius = c->dgrid_radius[0];
   a.dgrid2 = c->dgrid[1];
   a.dgrid2_radius = c->dgrid_radius[1];
+  a.fgrid = c->fgrid;
   a.f32_delta = c->f32_delta;
   a.f32_range = c->f32_range;
   a.f32_delta_fk = c->f32_delta_fk;
@@ -744,6 +774,28 @@ extern "C" int mvk_broadphase_query(const mvk_box* boxes, size_t n_boxes, double
   return MVK_OK;
 }
 
+extern "C" int mvk_far_grid_query(const mvk_box* boxes, size_t n_boxes, double reach, double margin, const double* points,
+                                  size_t n_points, int32_t* counts, int32_t* ids, int cap) {
+  if (!(reach >= 0.0) || !(margin >= 0.0) || (n_points && (!points || !counts)) || cap < 0 || (cap > 0 && !ids))
+    return fail(MVK_ERR_INVALID_ARG, "mvk_far_grid_query: bad argument");
+  std::vector<DevObs> host;
+  if (int rc = boxes_to_obs(boxes, n_boxes, host)) return rc;
+  GridHost g;
+  if (int rc = build_far_grid(host.data(), n_boxes, reach, margin, 1e-6, g)) return rc;
+  for (size_t i = 0; i < n_points; ++i) {
+    const uint16_t* list = nullptr;
+    const int padded = grid_query(g, points + 3 * i, &list);
+    int k = 0;
+    for (int e = 0; e < padded; ++e)
+      if (list[e] != kGridNone) {
+        if (k < cap) ids[i * static_cast<size_t>(cap) + k] = list[e];
+        ++k;
+      }
+    counts[i] = padded ? k : -1;  // (a cell's list is never empty: it holds the box nearest to its centre)
+  }
+  return MVK_OK;
+}
+
 extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, size_t n_boxes,
                                const mvk_params* params, int device) {
   if (!model || !params) {
@@ -831,7 +883,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
   if (c->order_ev) (void)hipEventDestroy(c->order_ev);
   if (c->d_model) (void)hipFree(c->d_model);
   if (c->d_extras) (void)hipFree(c->d_extras);
-  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start[0], &c->dgrid_items[0], &c->dgrid_start[1], &c->dgrid_items[1], &c->queue, &c->queue_rec, &c->queue_counts, &c->refine_list, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
+  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start[0], &c->dgrid_items[0], &c->dgrid_start[1], &c->dgrid_items[1], &c->fgrid_start, &c->fgrid_items, &c->queue, &c->queue_rec, &c->queue_counts, &c->refine_list, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
                 &c->partial, &c->stats_out, &c->full_rec, &c->small_done, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
   for (Buf* b : all) b->release();
@@ -847,6 +899,7 @@ extern "C" int mvk_set_scene(mvk_ctx* c, const mvk_box* boxes, size_t n_boxes) {
   if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
   HIP_TRY(hipSetDevice(c->device));
+  if (int rc = wait_last_call(c)) return rc;  // the last call may be on a caller's stream and still reading the old scene
   HIP_TRY(hipStreamSynchronize(c->stream));
   return upload_scene(c, boxes, n_boxes);
 }
@@ -1142,7 +1195,7 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
   // Full path on a handful of states without detail rows (mvk_is_valid, clearance queries): the kernels read the rows
   // from, and write the outputs to, pinned host memory, and the last block of distance_small_kernel raises the done
   // word -- no copy, no stream synchronisation
-  if (!det && n <= 1024 && (force_full || min_dist || margin || band)) {
+  if (!det && n <= 1024 && n <= c->small_full_max && (force_full || min_dist || margin || band)) {
     EvalArgs probe;
     base_args(c, probe);
     if (probe.do_coll && probe.n_obs > 0 && c->small_full_enabled) {

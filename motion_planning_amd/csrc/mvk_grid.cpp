@@ -17,8 +17,10 @@
 // items[]; every cell's list is padded to whole groups with kGridNone so that a
 // lane fetches kGridGroup candidates with one aligned 8-byte load.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 #include "mvk_internal.h"
 
@@ -124,6 +126,104 @@ int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g) {
     return MVK_OK;
   }
   return fail(MVK_ERR_CAPACITY, "broadphase grid does not fit its budget (scene too large or too dense)");
+}
+
+// Far grid: nearest-candidate lists that need no radius.  With l(x, b) the distance from point x to box b and
+// lmin(x) its minimum over the boxes, the cell holding x lists every box with l(x, b) <= lmin(x) + reach: whatever
+// primitive of bounding radius <= reach is centred at x, the boxes that can realise its minimum distance (lower
+// bound l - reach, upper bound lmin) are all in the list, however far away they are.  l is 1-Lipschitz in x, so
+// with m the cell's centre and rc its half diagonal the list {b : l(m, b) <= lmin(m) + 2 rc + reach} covers every
+// point of the cell.  The volume is the boxes' bound inflated by `margin`; points outside it are not answered
+// (grid_query returns 0 there, the kernels fall back to the sweep over all boxes).
+int build_far_grid(const DevObs* obs, size_t n, double reach, double margin, double pad, GridHost& g) {
+  g.start.clear();
+  g.items.clear();
+  g.radius = INFINITY;
+  for (int k = 0; k < 3; ++k) { g.origin[k] = 0.0; g.n[k] = 1; }
+  g.h = 1.0;
+  if (n == 0 || n >= kGridNone) return fail(MVK_ERR_CAPACITY, "far grid: no boxes, or more than the 16-bit ids hold");
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::min(lo[k], obs[i].c[k] - obs[i].bound - margin);
+      hi[k] = std::max(hi[k], obs[i].c[k] + obs[i].bound + margin);
+    }
+  // cells: as many as keep (cells x boxes) cheap tests affordable at scene set-up
+  const double want = std::min(24576.0, std::max(4096.0, 6.0e7 / static_cast<double>(n)));
+  const double vol = (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]);
+  const double h = std::max(std::cbrt(vol / want), 1e-3);
+  int dim[3];
+  uint64_t ncell = 1;
+  for (int k = 0; k < 3; ++k) {
+    dim[k] = std::max(1, static_cast<int>(std::ceil((hi[k] - lo[k]) / h)));
+    ncell *= static_cast<uint64_t>(dim[k]);
+  }
+  if (ncell > (1u << 20)) return fail(MVK_ERR_CAPACITY, "far grid: volume too elongated for its cell budget");
+  // (slack for the rounding of the device's cell-index computation, as build_grid)
+  const double rc = 0.5 * h * std::sqrt(3.0) * (1.0 + 1e-9) + 1e-7;
+  const double add = 2.0 * rc + reach + pad;
+  std::vector<std::vector<uint16_t>> lists(ncell);
+  std::atomic<uint64_t> next{0};
+  auto work = [&]() {
+    std::vector<std::pair<uint16_t, double>> near;
+    for (;;) {
+      const uint64_t c = next.fetch_add(1);
+      if (c >= ncell) break;
+      const int x = static_cast<int>(c % dim[0]), y = static_cast<int>((c / dim[0]) % dim[1]), z = static_cast<int>(c / (static_cast<uint64_t>(dim[0]) * dim[1]));
+      const double m[3] = {lo[0] + (x + 0.5) * h, lo[1] + (y + 0.5) * h, lo[2] + (z + 0.5) * h};
+      // cheap pass: a box's centre lies in it, so |m - centre| bounds l(m, b) from above, and minus the box's
+      // bounding radius from below
+      double up = INFINITY;
+      for (size_t b = 0; b < n; ++b) {
+        const double d[3] = {m[0] - obs[b].c[0], m[1] - obs[b].c[1], m[2] - obs[b].c[2]};
+        up = std::min(up, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      }
+      up = std::sqrt(up);
+      near.clear();
+      double lmin = INFINITY;
+      for (size_t b = 0; b < n; ++b) {
+        const DevObs& o = obs[b];
+        const double d[3] = {m[0] - o.c[0], m[1] - o.c[1], m[2] - o.c[2]};
+        const double cd = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (cd - o.bound > up + add) continue;
+        double s2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+          const double t = std::fabs(o.R[a] * d[0] + o.R[3 + a] * d[1] + o.R[6 + a] * d[2]) - o.h[a];
+          if (t > 0.0) s2 += t * t;
+        }
+        const double l = std::sqrt(s2);
+        lmin = std::min(lmin, l);
+        near.emplace_back(static_cast<uint16_t>(b), l);
+      }
+      std::vector<uint16_t>& out = lists[c];
+      for (const auto& e : near)
+        if (e.second <= lmin + add) out.push_back(e.first);  // ascending ids
+    }
+  };
+  {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+  }
+  uint64_t groups = 0;
+  for (uint64_t c = 0; c < ncell; ++c) groups += (lists[c].size() + kGridGroup - 1) / kGridGroup;
+  // (group indices travel in 21 bits of the distance kernels' ring items)
+  if (groups >= (1u << 21) || groups * kGridGroup > kGridMaxItems) return fail(MVK_ERR_CAPACITY, "far grid: lists beyond the budget");
+  g.start.assign(ncell + 1, 0u);
+  uint32_t at = 0;
+  for (uint64_t c = 0; c < ncell; ++c) {
+    g.start[c] = at;
+    at += static_cast<uint32_t>((lists[c].size() + kGridGroup - 1) / kGridGroup);
+  }
+  g.start[ncell] = at;
+  g.items.assign(static_cast<size_t>(at) * kGridGroup, static_cast<uint16_t>(kGridNone));
+  for (uint64_t c = 0; c < ncell; ++c) std::copy(lists[c].begin(), lists[c].end(), g.items.begin() + static_cast<size_t>(g.start[c]) * kGridGroup);
+  for (int k = 0; k < 3; ++k) { g.origin[k] = lo[k]; g.n[k] = dim[k]; }
+  g.h = h;
+  return MVK_OK;
 }
 
 int grid_query(const GridHost& g, const double c[3], const uint16_t** ids) {

@@ -93,6 +93,9 @@ struct GridHost {
 };
 // every box within `radius` of a point is listed in the cell holding the point
 int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g);
+// far grid: the cell holding a point x lists every box b with l(x, b) <= reach + min over boxes of l(x, .), inside the
+// boxes' bound inflated by `margin` (pad: slack for the device's fp32 centre distances)
+int build_far_grid(const DevObs* obs, size_t n, double reach, double margin, double pad, GridHost& g);
 // host lookup (tests / diagnostics): returns the padded candidate count, ids in *ids
 int grid_query(const GridHost& g, const double c[3], const uint16_t** ids);
 
@@ -184,6 +187,7 @@ struct EvalArgs {
   uint32_t small_target;  // host_done set: the block that brings *fused_done to this count raises the done word
   GridDev dgrid2;
   double dgrid2_radius;
+  GridDev fgrid;          // far grid (start == nullptr: none): complete nearest-candidate lists at any distance, inside its volume
   // C-space sweep (mvk_sweep_mask_dev): states are generated from the sample index, nothing is read
   int32_t sweep_on;
   uint64_t sweep_first, sweep_seed;

@@ -1307,6 +1307,21 @@ DEV void grid_cell(const GridDev& G, const double c[3], bool on, unsigned& gb, u
   }
 }
 
+// the same, and whether the point lies inside the grid's volume (the far grid answers only there)
+DEV bool grid_cell_in(const GridDev& G, const double c[3], bool on, unsigned& gb, unsigned& ge) {
+  const double gx = (c[0] - G.origin[0]) * G.inv_h, gy = (c[1] - G.origin[1]) * G.inv_h, gz = (c[2] - G.origin[2]) * G.inv_h;
+  const bool inside = on && G.start != nullptr && gx >= 0.0 && gy >= 0.0 && gz >= 0.0 && gx < static_cast<double>(G.n[0]) &&
+                      gy < static_cast<double>(G.n[1]) && gz < static_cast<double>(G.n[2]);
+  gb = 0; ge = 0;
+  if (inside) {
+    const unsigned cell = (static_cast<unsigned>(static_cast<int>(gz)) * G.n[1] + static_cast<unsigned>(static_cast<int>(gy))) * G.n[0] +
+                          static_cast<unsigned>(static_cast<int>(gx));
+    gb = G.start[cell];
+    ge = G.start[cell + 1];
+  }
+  return inside;
+}
+
 // fp32 squared distance from a point to a world box
 DEV float point_box_dist2_f32(const DevObsF& F, float x, float y, float z) {
   const float dx = x - F.c[0], dy = y - F.c[1], dz = z - F.c[2];
@@ -1703,17 +1718,18 @@ DEV bool exact_pair(const mvk_model* __restrict__ M, const DevExtras* __restrict
 // grid_collect_nearest: both steps in one pass over the cell's list, for the avoidance rows (no bound is known
 // beforehand there: the primitive's own nearest box sets it).  The threshold follows the running minimum, so the
 // list also keeps a few boxes met before the nearest one -- the drain's separating-axis gaps discard them.
-DEV bool grid_collect_nearest(const EvalArgs& A, const Smem& sm, bool on, const double pc[3], double rb, int& cnt, unsigned& gb, unsigned& ge) {
+DEV bool grid_collect_nearest(const EvalArgs& A, const GridDev& G, double radius, const Smem& sm, bool on, const double pc[3], double rb,
+                              int& cnt, unsigned& gb, unsigned& ge) {
   const int tid = threadIdx.x;
   const DevObsF* __restrict__ obsf = A.obsf;
-  grid_cell(A.dgrid, pc, on, gb, ge);
+  const bool inside = grid_cell_in(G, pc, on, gb, ge);
   const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
   const float rbf = static_cast<float>(rb) * 1.000001f + 2.0f * A.f32_delta;
   float best2f = INFINITY, thr2f = INFINITY;
   int n = 0;
 #pragma unroll 1
   for (unsigned g = gb; g < ge; ++g) {
-    const ushort4 v = *reinterpret_cast<const ushort4*>(A.dgrid.items + static_cast<size_t>(g) * kGridGroup);
+    const ushort4 v = *reinterpret_cast<const ushort4*>(G.items + static_cast<size_t>(g) * kGridGroup);
     const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < kGridGroup; ++e) {
@@ -1732,7 +1748,7 @@ DEV bool grid_collect_nearest(const EvalArgs& A, const Smem& sm, bool on, const 
     }
   }
   const double up = static_cast<double>(sqrtf(best2f)) * 1.000001 + static_cast<double>(A.f32_delta);
-  if (!(on && rb + up + 2.0 * static_cast<double>(A.f32_delta) <= A.dgrid_radius)) return false;
+  if (!(inside && best2f < INFINITY && rb + up + 2.0 * static_cast<double>(A.f32_delta) <= radius)) return false;  // (+inf: nothing listed)
   cnt = n;
   return true;
 }
@@ -1827,6 +1843,57 @@ DEV void sweep_for_lanes_f32(const EvalArgs& A, const Smem& sm, bool scan, const
   __builtin_amdgcn_wave_barrier();
 }
 
+// The far grid for the lanes the distance grid could not answer (`scan`: those inside its volume, cell groups
+// gb .. ge): the same two passes over the cell's list instead of all boxes.  A list is a few dozen boxes, so the wave
+// serves one lane at a time, every lane taking one entry per round: the nearest box's centre distance (wave
+// minimum), then the entries within the threshold it sets, appended to the served lane's list in list order
+// (ascending ids).
+DEV void far_for_lanes_f32(const EvalArgs& A, const Smem& sm, bool scan, const double pc[3], double rb, unsigned gb, unsigned ge, int& cnt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave_tid = tid - lane;
+  unsigned long long todo = __ballot(scan);
+  if (todo == 0ull) return;
+  const DevObsF* __restrict__ obsf = A.obsf;
+  const uint16_t* __restrict__ items = A.fgrid.items;
+  const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
+  const float rbf = static_cast<float>(rb) * 1.000001f + 2.0f * A.f32_delta;
+  int n = 0;
+#pragma unroll 1
+  while (todo) {
+    const int src = __ffsll(static_cast<long long>(todo)) - 1;
+    todo &= todo - 1ull;
+    const float cx = bcast_lane(x, src), cy = bcast_lane(y, src), cz = bcast_lane(z, src), crb = bcast_lane(rbf, src);
+    const unsigned b0 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(gb), src)) * kGridGroup;
+    const unsigned b1 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(ge), src)) * kGridGroup;
+    float acc = INFINITY;
+#pragma unroll 1
+    for (unsigned e = b0 + static_cast<unsigned>(lane); e < b1; e += 64u) {
+      const unsigned id = items[e];
+      if (id != static_cast<unsigned>(kGridNone)) acc = fminf(acc, point_box_dist2_f32(obsf[id], cx, cy, cz));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc = fminf(acc, __shfl_xor(acc, o));
+    const float t = (crb + sqrtf(acc) * 1.000001f) * 1.000001f;
+    const float thr2 = t * t;
+    int cn = 0;
+#pragma unroll 1
+    for (unsigned base = b0; base < b1; base += 64u) {
+      const unsigned e = base + static_cast<unsigned>(lane);
+      const unsigned id = e < b1 ? items[e] : static_cast<unsigned>(kGridNone);
+      const bool pass = id != static_cast<unsigned>(kGridNone) && point_box_dist2_f32(obsf[id], cx, cy, cz) <= thr2;
+      const unsigned long long pm = __ballot(pass);
+      if (pass) {
+        const int slot = cn + __popcll(pm & ((1ull << lane) - 1ull));
+        if (slot < kListCap) sm.list[slot * kBlock + wave_tid + src] = static_cast<unsigned short>(id);
+      }
+      cn += __popcll(pm);
+    }
+    if (lane == src) n = cn;
+  }
+  if (scan) cnt = n;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // The same sweep in fp64 for lanes beyond the coordinate range the fp32 bounds are trusted for, one such lane at a time: lane i takes boxes i, i + 64, ...; a wave minimum gives the centre's distance to the
 // nearest box (best2, exact fp64), and the boxes that can still undercut min(bound, that distance) are
 // appended to the source lane's candidate list in ascending order.  ~2 * n_obs / 64 rounds per lane served
@@ -1908,8 +1975,9 @@ DEV void dist_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const Sme
     wt = sm.dring[5 * kRing + at];
   }
   const unsigned g0 = wa & 0x1FFFFFu, src = (wa >> 21) & 63u, slot = (wa >> 27) & 15u;
-  const bool all = wa >> 31, wide = wb >> 31;  // the range's kind: all boxes in order / a cell of the wider second grid / a cell of the grid
-  const unsigned ge = wb & 0x7FFFFFFFu;
+  // the range's kind: all boxes in order / a cell of the wider second grid / a cell of the far grid / a cell of the grid
+  const bool all = wa >> 31, wide = wb >> 31, farg = (wb >> 30) & 1u;
+  const unsigned ge = wb & 0x3FFFFFFFu;
   const unsigned g = g0 + sub;
   if (active && g < ge) {
     unsigned ids[kGridGroup];
@@ -1920,7 +1988,7 @@ DEV void dist_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const Sme
         ids[e] = id < static_cast<unsigned>(A.n_obs) ? id : static_cast<unsigned>(kGridNone);
       }
     } else {
-      const uint2 w = *reinterpret_cast<const uint2*>((wide ? A.dgrid2.items : A.dgrid.items) + static_cast<size_t>(g) * kGridGroup);
+      const uint2 w = *reinterpret_cast<const uint2*>((wide ? A.dgrid2.items : farg ? A.fgrid.items : A.dgrid.items) + static_cast<size_t>(g) * kGridGroup);
       ids[0] = w.x & 0xFFFFu; ids[1] = w.x >> 16; ids[2] = w.y & 0xFFFFu; ids[3] = w.y >> 16;
     }
     DevObsF F[kGridGroup];
@@ -1965,8 +2033,8 @@ DEV void dist_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const Sme
 }
 
 // one item per lane that wants one (wave-uniform head / qn)
-// kind of a range: a cell of the distance grid, a cell of the wider second grid, all boxes in order
-constexpr unsigned kRangeCell = 0u, kRangeWide = 1u, kRangeAll = 2u;
+// kind of a range: a cell of the distance grid, a cell of the wider second grid, all boxes in order, a cell of the far grid
+constexpr unsigned kRangeCell = 0u, kRangeWide = 1u, kRangeAll = 2u, kRangeFar = 3u;
 DEV void dist_push(const Smem& sm, bool want, const double pc[3], unsigned gb, unsigned ge, unsigned slot, unsigned kind, float thr2,
                    unsigned head, unsigned& qn) {
   const int lane = threadIdx.x & 63;
@@ -1979,7 +2047,7 @@ DEV void dist_push(const Smem& sm, bool want, const double pc[3], unsigned gb, u
       sm.dring[1 * kRing + to] = __float_as_uint(static_cast<float>(pc[1]));
       sm.dring[2 * kRing + to] = __float_as_uint(static_cast<float>(pc[2]));
       sm.dring[3 * kRing + to] = gb | (static_cast<unsigned>(lane) << 21) | (slot << 27) | (kind == kRangeAll ? 1u << 31 : 0u);
-      sm.dring[4 * kRing + to] = ge | (kind == kRangeWide ? 1u << 31 : 0u);
+      sm.dring[4 * kRing + to] = ge | (kind == kRangeWide ? 1u << 31 : 0u) | (kind == kRangeFar ? 1u << 30 : 0u);
       sm.dring[5 * kRing + to] = __float_as_uint(thr2);
     }
     qn += static_cast<unsigned>(__popcll(bal));
@@ -2105,6 +2173,9 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
           if (far && have_wide && thr0 + dd <= A.dgrid2_radius) {
             grid_cell(A.dgrid2, pc, true, far_b, far_e);
             far_kind = kRangeWide;
+          } else if (far) {  // ... or the far grid, whose cell lists the boxes that can be nearest at any distance
+            unsigned fb, fe;
+            if (grid_cell_in(A.fgrid, pc, true, fb, fe)) { far_b = fb; far_e = fe; far_kind = kRangeFar; }
           }
           if (far) *up_slot = 0x7F800000u;
           dist_push(sm, far, pc, far_b, far_e, static_cast<unsigned>(qi < kUpperSlots ? qi : kUpperSlots - 1), far_kind, 0.0f, head, qn);
@@ -3787,6 +3858,12 @@ DEV double distance_small_body(const EvalArgs& A, const mvk_model* __restrict__ 
       todo = todo && !(rb + fmax(best, 0.0) + pad <= A.dgrid2_radius);
     }
   }
+  if (A.fgrid.start != nullptr && __any(todo)) {  // the far grid: complete at any distance, inside its volume
+    unsigned gb, ge;
+    const bool inside = grid_cell_in(A.fgrid, pc, todo, gb, ge);
+    scan(A.fgrid.items + static_cast<size_t>(gb) * kGridGroup, static_cast<int>(ge - gb) * kGridGroup);
+    todo = todo && !inside;
+  }
   if (__any(todo)) scan(nullptr, todo ? A.n_obs : 0);
   const double mind = group_min(best);
   return mind;
@@ -3981,9 +4058,21 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       int cnt = 0;
       unsigned cell_b = 0, cell_e = 0;
       bool from_grid = false;
+      const uint16_t* __restrict__ cell_items = A.dgrid.items;
       if (use_grid) {
         bool scan = in_range;
-        if (grid_collect_nearest(A, sm, in_range && f32_safe, pc, rb, cnt, cell_b, cell_e)) scan = false;
+        if (grid_collect_nearest(A, A.dgrid, A.dgrid_radius, sm, in_range && f32_safe, pc, rb, cnt, cell_b, cell_e)) scan = false;
+        if (A.fgrid.start != nullptr && __any(scan && f32_safe)) {  // too far for the grid's radius: the far grid's list
+          int c3 = 0;
+          unsigned b3 = 0, e3 = 0;
+          const bool inside = grid_cell_in(A.fgrid, pc, scan && f32_safe, b3, e3);
+          far_for_lanes_f32(A, sm, inside, pc, rb, b3, e3, c3);
+          if (inside) {
+            scan = false;
+            cnt = c3; cell_b = b3; cell_e = e3;
+            cell_items = A.fgrid.items;
+          }
+        }
         from_grid = !scan;
         double b2 = INFINITY;
         int c2 = 0;
@@ -4018,7 +4107,7 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       const bool from_cell = overflow && from_grid && in_range;
       const int todo = (use_grid && !in_range) ? 0 : (overflow ? (from_cell ? static_cast<int>(cell_e - cell_b) * kGridGroup : A.n_obs) : cnt);
       auto cand = [&](int e) -> int {  // kGridNone: padding, skip
-        return !overflow ? sm.list[e * kBlock + tid] : (from_cell ? A.dgrid.items[static_cast<size_t>(cell_b) * kGridGroup + e] : e);
+        return !overflow ? sm.list[e * kBlock + tid] : (from_cell ? cell_items[static_cast<size_t>(cell_b) * kGridGroup + e] : e);
       };
       PROF_CLK(0, t_c);
       PROF_T0(t_d);
@@ -4535,48 +4624,56 @@ avoid_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevE
     merge(false);
     todo = active && !(rb + fmax(cut, 0.0) + 2.0 * kSatSlack <= A.dgrid_radius);
   }
-  if (__any(todo)) {
-    // The sweep over all boxes.  First the box nearest to the primitive's centre: its distance bounds the primitive's
-    // from above.  Then the boxes whose centre distance can undercut that are collected per lane (a cheap pass:
-    // one in a few dozen survives) and only those go through the narrowphase, which the wave runs in lockstep.
+  // The sweep over a complete set of boxes (`ids`: a far-grid cell's list; nullptr: all boxes in order) for the lanes
+  // `who`.  First the box nearest to the primitive's centre: its distance bounds the primitive's from above.  Then the
+  // boxes whose centre distance can undercut that are collected per lane (a cheap pass: one in a few dozen survives)
+  // and only those go through the narrowphase, which the wave runs in lockstep.
+  auto sweep = [&](bool who, const uint16_t* __restrict__ ids, int n_items) {
+    auto box_at = [&](int e) -> int { return ids ? static_cast<int>(ids[e]) : e; };
     double l2min = INFINITY;
-    int emin = -1;
+    int bmin = -1;
 #pragma unroll 1
-    for (int e = part; __any(todo && e < A.n_obs); e += K)
-      if (todo && e < A.n_obs) {
-        double t[3];
-        to_box_frame(obs[e], pc, t);
-        const double l2 = point_box_dist2(t, obs[e].h);
-        if (l2 < l2min) { l2min = l2; emin = e; }
+    for (int e = part; __any(who && e < n_items); e += K)
+      if (who && e < n_items) {
+        const int ob = box_at(e);
+        if (ob != kGridNone) {
+          double t[3];
+          to_box_frame(obs[ob], pc, t);
+          const double l2 = point_box_dist2(t, obs[ob].h);
+          if (l2 < l2min) { l2min = l2; bmin = ob; }
+        }
       }
     red[lane * kRed] = l2min;
-    red[lane * kRed + 1] = static_cast<double>(emin);
+    red[lane * kRed + 1] = static_cast<double>(bmin);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
     for (int j = 0; j < K; ++j) {
       const double l2 = red[(qi + j * P) * kRed];
-      if (l2 < l2min) { l2min = l2; emin = static_cast<int>(red[(qi + j * P) * kRed + 1]); }
+      if (l2 < l2min) { l2min = l2; bmin = static_cast<int>(red[(qi + j * P) * kRed + 1]); }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (todo) cut = fmin(cut, sqrt(l2min) * (1.0 + 1e-12));
-    process(todo && part == 0 && emin >= 0 ? emin : kGridNone);  // (emin < 0: an empty scene)
+    if (who) cut = fmin(cut, sqrt(l2min) * (1.0 + 1e-12));
+    process(who && part == 0 && bmin >= 0 ? bmin : kGridNone);  // (bmin < 0: an empty scene)
     merge(false);
     int e = part;
 #pragma unroll 1
-    while (__any(todo && e < A.n_obs)) {
+    while (__any(who && e < n_items)) {
       int cnt = 0;
       const double thr = rb + fmax(cut, 0.0) + kSatSlack;
       const double thr2 = thr * thr * (1.0 + 1e-12);
 #pragma unroll 1
-      while (__any(todo && e < A.n_obs && cnt < kSweepKeep)) {
-        if (todo && e < A.n_obs && cnt < kSweepKeep) {
-          double t[3];
-          to_box_frame(obs[e], pc, t);
-          if (point_box_dist2(t, obs[e].h) <= thr2) {
-            keep[cnt * 64 + lane] = static_cast<unsigned short>(e);
-            ++cnt;
+      while (__any(who && e < n_items && cnt < kSweepKeep)) {
+        if (who && e < n_items && cnt < kSweepKeep) {
+          const int ob = box_at(e);
+          if (ob != kGridNone) {
+            double t[3];
+            to_box_frame(obs[ob], pc, t);
+            if (point_box_dist2(t, obs[ob].h) <= thr2) {
+              keep[cnt * 64 + lane] = static_cast<unsigned short>(ob);
+              ++cnt;
+            }
           }
           e += K;
         }
@@ -4585,7 +4682,14 @@ avoid_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevE
       for (int i = 0; __any(i < cnt); ++i) process(i < cnt ? static_cast<int>(keep[i * 64 + lane]) : kGridNone);
       merge(false);
     }
+  };
+  if (A.fgrid.start != nullptr && __any(todo)) {  // the far grid: complete at any distance, inside its volume
+    unsigned gb, ge;
+    const bool inside = grid_cell_in(A.fgrid, pc, todo, gb, ge);
+    sweep(inside, A.fgrid.items + static_cast<size_t>(gb) * kGridGroup, static_cast<int>(ge - gb) * kGridGroup);
+    todo = todo && !inside;
   }
+  if (__any(todo)) sweep(todo, nullptr, A.n_obs);
   merge(true);
 
   const bool report = active && part == 0;

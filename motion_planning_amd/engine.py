@@ -83,6 +83,18 @@ def broadphase_query(boxes, radius, points, cap=256):
     return counts, ids
 
 
+def far_grid_query(boxes, reach, margin, points, cap=1024):
+    """Host diagnostic: ids the far grid lists for each query point ([n, 3]); counts -1 outside its volume."""
+    lib = A.load()
+    arr, m = boxes_from_array(boxes)
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    counts = np.zeros(len(pts), np.int32)
+    ids = np.full((len(pts), cap), -1, np.int32)
+    _check(lib, lib.mvk_far_grid_query(arr, m, float(reach), float(margin), pts.ctypes.data_as(C.c_void_p), len(pts),
+                                       counts.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), cap))
+    return counts, ids
+
+
 def sweep_states(params, n_joint, root_pose7, first_index, n, seed):
     """The states of the C-space sweep, materialised on the host ([7+J, n], POSE7 rows); no device needed."""
     lib = A.load()
