@@ -4282,7 +4282,7 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
             double t[3], pr[3], pq[3];
             to_box_frame(O, pc, t);
             const double d = narrow_cp(type, PR, d0, d1, d2, O, t, pr, pq, best);
-            if (d < best) {  // ascending box order, strict: the first minimum wins, as in the oracle
+            if (d < best || (d == best && ob < bi)) {  // the first minimum in ascending box order, as in the oracle, whatever the list's order
               best = d;
               bi = ob;
 #pragma unroll
@@ -4628,7 +4628,20 @@ avoid_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevE
   // `who`.  First the box nearest to the primitive's centre: its distance bounds the primitive's from above.  Then the
   // boxes whose centre distance can undercut that are collected per lane (a cheap pass: one in a few dozen survives)
   // and only those go through the narrowphase, which the wave runs in lockstep.
-  auto sweep = [&](bool who, const uint16_t* __restrict__ ids, int n_items) {
+  // (two stages through one body: the far grid's cell for the lanes inside its volume, then all boxes for the rest)
+#pragma unroll 1
+  for (int stage = 0; stage < 2; ++stage) {
+    bool who = todo;
+    const uint16_t* __restrict__ ids = nullptr;
+    int n_items = A.n_obs;
+    if (stage == 0) {
+      if (A.fgrid.start == nullptr) continue;
+      unsigned gb, ge;
+      who = grid_cell_in(A.fgrid, pc, todo, gb, ge);
+      ids = A.fgrid.items + static_cast<size_t>(gb) * kGridGroup;
+      n_items = static_cast<int>(ge - gb) * kGridGroup;
+    }
+    if (!__any(who)) continue;
     auto box_at = [&](int e) -> int { return ids ? static_cast<int>(ids[e]) : e; };
     double l2min = INFINITY;
     int bmin = -1;
@@ -4682,14 +4695,8 @@ avoid_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevE
       for (int i = 0; __any(i < cnt); ++i) process(i < cnt ? static_cast<int>(keep[i * 64 + lane]) : kGridNone);
       merge(false);
     }
-  };
-  if (A.fgrid.start != nullptr && __any(todo)) {  // the far grid: complete at any distance, inside its volume
-    unsigned gb, ge;
-    const bool inside = grid_cell_in(A.fgrid, pc, todo, gb, ge);
-    sweep(inside, A.fgrid.items + static_cast<size_t>(gb) * kGridGroup, static_cast<int>(ge - gb) * kGridGroup);
-    todo = todo && !inside;
+    todo = todo && !who;
   }
-  if (__any(todo)) sweep(todo, nullptr, A.n_obs);
   merge(true);
 
   const bool report = active && part == 0;
