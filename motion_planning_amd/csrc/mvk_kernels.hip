@@ -4001,8 +4001,11 @@ full_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevEx
 // per collision primitive the minimum distance over the world boxes with nearest points (:147-153),
 // the normal from the environment to the robot (:255), the row n^T J_lin over
 // [root v (world), root w (world), planned joints] (:259-260) and the damped bound (:262-265).
+#ifndef MVK_AVOID_WAVES
+#define MVK_AVOID_WAVES 2
+#endif
 template <int ROBOT, int NL>
-__global__ void __launch_bounds__(kBlock, 2)  // as the full kernel: occupancy over spills
+__global__ void __launch_bounds__(kBlock, MVK_AVOID_WAVES)  // as the full kernel: occupancy over spills
 avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
              const DevObs* __restrict__ obs) {
   using S = Shape<ROBOT, NL>;
