@@ -392,16 +392,38 @@ def bench_edges(args, world, rank, local_rank, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        print(json.dumps({
+        emit_line({
             "metric": "state validity checks/sec", "value": world * E * nd * args.steps / elapsed, "unit": "checks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"c4: HYDRUS 6-link edge checks, {E} edges/GPU x {nd} interpolation steps, 100 box obstacles",
                        "edges_per_gpu": E, "steps_per_edge": nd, "parallelism": f"shard{world} (by edge)"},
-            "edges_per_s": world * E * args.steps / elapsed, "valid_edge_fraction": float(ok.float().mean().item())}))
+            "edges_per_s": world * E * args.steps / elapsed, "valid_edge_fraction": float(ok.float().mean().item())})
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+_JSON_FD = None
+
+
+def claim_stdout():
+    """stdout carries the one JSON line and nothing else: whatever the libraries print there from now on (RCCL's
+    version banner at communicator set-up, for one) goes to stderr"""
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit_line(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_JSON_FD, data)
 
 
 def main():
@@ -422,6 +444,7 @@ def main():
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="one rank: run the step's RCCL exchange (a group of one) exactly as the N > 1 path issues it")
     args = ap.parse_args()
+    claim_stdout()
 
     import torch
     import torch.distributed as dist
@@ -538,10 +561,26 @@ def main():
         split.append(eng.last_kernel_ms())
     screen_ms = float(np.mean([x[0] for x in split]))
     exact_ms = float(np.mean([x[1] for x in split]))
+    exchange_ms = None
     if exchange:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the exchange on its own (reported separately): count kernel + mask all-gather + count
+        # all-reduce, back to back on the exchange stream, every rank
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        with torch.cuda.stream(side):
+            e0.record(side)
+            for _ in range(10):
+                eng.mask_count_dev(d_masks[0], n, d_cnts[0])
+                dist.all_gather_into_tensor(d_alls[0], d_masks[0])
+                dist.all_reduce(d_cnts[0])
+            e1.record(side)
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / 10], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange_ms = float(t.item())
 
     if rank == 0:
         valid = int(sum(bin(int(x) & 0xFFFFFFFFFFFFFFFF).count("1") for x in d_mask.cpu().numpy()[:4096]))
@@ -571,6 +610,7 @@ def main():
             last = (args.steps - 1) % n_slot
             out["valid_total_last_step"] = int(d_cnts[last].item())   # all-reduced over ranks (mvk_mask_count_dev + RCCL sum)
             out["exchange"] = "per step: all-gather of the packed mask + all-reduce of the valid count, overlapped with the next step's kernels"
+            out["exchange_ms"] = exchange_ms   # one exchange alone (max over ranks): what the overlap hides
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w)
         if not args.no_planner and world == 1:
@@ -585,7 +625,7 @@ def main():
             out["single_calls"] = single_calls(eng, w)
         if not args.no_fp32 and world == 1 and not sweep:
             out["fp32_variant"] = fp32_variant(eng, w, d_soa, n, dev)
-        print(json.dumps(out))
+        emit_line(out)
     eng.close()
     if exchange:
         dist.destroy_process_group()
