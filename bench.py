@@ -54,8 +54,15 @@ def cpu_baseline(w, budget_s=12.0):
     t0 = time.perf_counter()
     O.flags_only(w.model, w.boxes, w.params, soa, w.layout, threads=cores)
     dt = time.perf_counter() - t0
+    # one thread as well (SURVEY.md 8(d) asks for both), on ~3 s of work
+    n1 = int(min(n2, max(2000, rate / cores * 3.0)))
+    soa1 = np.ascontiguousarray(w.soa[:, :n1])
+    t0 = time.perf_counter()
+    O.flags_only(w.model, w.boxes, w.params, soa1, w.layout, threads=1)
+    dt1 = time.perf_counter() - t0
     return {"value": n2 / dt, "unit": "checks/s", "cores": cores, "kind": "port",
-            "sample": f"first {n2} samples of the {w.name} batch, flag-only predicate, {cores} threads"}
+            "sample": f"first {n2} samples of the {w.name} batch, flag-only predicate, {cores} threads",
+            "single_thread": {"value": n1 / dt1, "unit": "checks/s", "sample": f"first {n1} samples, 1 thread"}}
 
 
 def rrt_connect_gap_pass(seeds=10, batch=256):
