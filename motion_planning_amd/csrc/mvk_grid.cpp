@@ -163,9 +163,13 @@ int build_far_grid(const DevObs* obs, size_t n, double reach, double margin, dou
   const double rc = 0.5 * h * std::sqrt(3.0) * (1.0 + 1e-9) + 1e-7;
   const double add = 2.0 * rc + reach + pad;
   std::vector<std::vector<uint16_t>> lists(ncell);
+  // box centres and bounding radii as flat arrays: the cheap passes below stream over them
+  std::vector<double> cx(n), cy(n), cz(n), bd(n);
+  for (size_t b = 0; b < n; ++b) { cx[b] = obs[b].c[0]; cy[b] = obs[b].c[1]; cz[b] = obs[b].c[2]; bd[b] = obs[b].bound; }
   std::atomic<uint64_t> next{0};
   auto work = [&]() {
     std::vector<std::pair<uint16_t, double>> near;
+    std::vector<double> d2(n);
     for (;;) {
       const uint64_t c = next.fetch_add(1);
       if (c >= ncell) break;
@@ -173,19 +177,21 @@ int build_far_grid(const DevObs* obs, size_t n, double reach, double margin, dou
       const double m[3] = {lo[0] + (x + 0.5) * h, lo[1] + (y + 0.5) * h, lo[2] + (z + 0.5) * h};
       // cheap pass: a box's centre lies in it, so |m - centre| bounds l(m, b) from above, and minus the box's
       // bounding radius from below
-      double up = INFINITY;
+      double up2 = INFINITY;
       for (size_t b = 0; b < n; ++b) {
-        const double d[3] = {m[0] - obs[b].c[0], m[1] - obs[b].c[1], m[2] - obs[b].c[2]};
-        up = std::min(up, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const double dx = m[0] - cx[b], dy = m[1] - cy[b], dz = m[2] - cz[b];
+        const double v = dx * dx + dy * dy + dz * dz;
+        d2[b] = v;
+        up2 = std::min(up2, v);
       }
-      up = std::sqrt(up);
+      const double T = std::sqrt(up2) + add;
       near.clear();
       double lmin = INFINITY;
       for (size_t b = 0; b < n; ++b) {
+        const double lim = T + bd[b];
+        if (d2[b] > lim * lim) continue;  // |m - centre| - bound > (upper bound of lmin) + add
         const DevObs& o = obs[b];
         const double d[3] = {m[0] - o.c[0], m[1] - o.c[1], m[2] - o.c[2]};
-        const double cd = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-        if (cd - o.bound > up + add) continue;
         double s2 = 0.0;
         for (int a = 0; a < 3; ++a) {
           const double t = std::fabs(o.R[a] * d[0] + o.R[3 + a] * d[1] + o.R[6 + a] * d[2]) - o.h[a];
@@ -196,6 +202,9 @@ int build_far_grid(const DevObs* obs, size_t n, double reach, double margin, dou
         near.emplace_back(static_cast<uint16_t>(b), l);
       }
       std::vector<uint16_t>& out = lists[c];
+      size_t keep = 0;
+      for (const auto& e : near) keep += e.second <= lmin + add;
+      out.reserve(keep);
       for (const auto& e : near)
         if (e.second <= lmin + add) out.push_back(e.first);  // ascending ids
     }
