@@ -661,7 +661,8 @@ int prepare_queue(mvk_ctx* c, EvalArgs& a, uint64_t n) {
 
 int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
                  uint64_t* d_mask, double* d_min_dist, double* d_margin, uint8_t* d_band,
-                 const mvk_detail_out* det, bool force_full, hipStream_t s, uint32_t poll_seq = 0) {
+                 const mvk_detail_out* det, bool force_full, hipStream_t s, uint32_t poll_seq = 0,
+                 const double* inline_rows = nullptr /* host rows of a single state, pitch 1: travel in the kernel arguments */) {
   if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
   if (n == 0) return MVK_OK;
@@ -694,6 +695,10 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
     // block of kBlock / kSmallGroup states)
     a.small_full = (a.do_coll && a.n_obs > 0 && !d_mask && n <= c->small_full_max && c->small_full_enabled) ? 1 : 0;
     if (a.small_full && n <= kFullOneLaunchMax) a.small_full = 2;  // walk 1 in the same launch, two states per block
+    if (a.small_full == 2 && n == 1 && inline_rows) {
+      a.inline_on = 1;
+      for (int r = 0; r < rows; ++r) a.inline_state[r] = inline_rows[r];
+    }
     const uint64_t stat_blocks = a.small_full == 2 ? (n + 1) / 2 : a.small_full ? (n + (kBlock / kSmallGroup) - 1) / (kBlock / kSmallGroup) : blocks;
     if (poll_seq) {  // eval_host: outputs in pinned memory, completion through the pinned done word
       if (!a.small_full) return fail(MVK_ERR_INVALID_ARG, "internal: polled completion asked of a call that does not take distance_small_kernel");
@@ -1148,6 +1153,10 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
       a.n = n;
       a.ld = dld;
       a.layout = layout;
+      if (n == 1) {  // a single state travels in the kernel arguments
+        a.inline_on = 1;
+        for (int r = 0; r < rows; ++r) a.inline_state[r] = soa[static_cast<size_t>(r) * ld];
+      }
       a.host_flags = static_cast<uint8_t*>(c->pin_down.p);
       a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
       a.fused_seq = next_seq(c);
@@ -1206,8 +1215,11 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
       unsigned char* down = static_cast<unsigned char*>(c->pin_down.p);
       double* down_d = reinterpret_cast<double*>(down + 2 * dld);
       const uint32_t seq = next_seq(c);
+      double one[MVK_MAX_STATE_DIM];
+      if (n == 1) for (int r = 0; r < rows; ++r) one[r] = soa[static_cast<size_t>(r) * ld];
       if (int rc = run_eval_dev(c, up, n, dld, layout, flags ? down : nullptr, nullptr, min_dist ? down_d : nullptr,
-                                margin ? down_d + dld : nullptr, band ? down + dld : nullptr, nullptr, force_full, s, seq))
+                                margin ? down_d + dld : nullptr, band ? down + dld : nullptr, nullptr, force_full, s, seq,
+                                n == 1 ? one : nullptr))
         return rc;
       int gave_up = 0;
       if (int rc = fused_wait(c, seq, s, &gave_up)) return rc;

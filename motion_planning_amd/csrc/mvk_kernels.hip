@@ -2614,7 +2614,8 @@ DEV void edge_step(const EvalArgs& A, uint64_t li, uint64_t& edge, int& step, in
 // State of global lane index li: a SoA batch row set, or step j of edge e densified in place
 // (lane -> (edge, step): step j in 1..nd tests interp(s1, s2, j/nd); j = nd is s2 itself).
 // WANT_JOINTS = false skips the joint rows (phase 2 of the flag path only needs the root pose).
-template <int NJ, bool EDGE, bool WANT_JOINTS>
+// INLINE: the kernel also serves host calls of one state whose rows travel in the kernel arguments (A.inline_on).
+template <int NJ, bool EDGE, bool WANT_JOINTS, bool INLINE = false>
 DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t& edge, int& step) {
   edge = 0;
   step = 0;
@@ -2637,11 +2638,13 @@ DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t
   }
   if (!EDGE) {
     const double* __restrict__ src = A.soa;
+    const bool inl = INLINE && A.inline_on;
+    auto row = [&](int r) -> double { return inl ? A.inline_state[r] : src[r * A.ld + li]; };
     if (A.layout == MVK_LAYOUT_POSE7) {
 #pragma unroll
-      for (int r = 0; r < 7; ++r) st[r] = src[r * A.ld + li];
+      for (int r = 0; r < 7; ++r) st[r] = row(r);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) st[7 + j] = WANT_JOINTS ? src[(7 + j) * A.ld + li] : 0.0;
+      for (int j = 0; j < NJ; ++j) st[7 + j] = WANT_JOINTS ? row(7 + j) : 0.0;
       if (A.planning_mode == MVK_MODE_ONLY_JOINTS) {
         st[0] = st[1] = st[2] = st[3] = st[4] = st[5] = 0.0; st[6] = 1.0;
       }
@@ -2653,11 +2656,11 @@ DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t
       double s[7];
       const int nb = (A.planning_mode == MVK_MODE_ONLY_JOINTS) ? 0 : (A.motion_type == MVK_SE2 ? 3 : 7);
 #pragma unroll
-      for (int r = 0; r < 7; ++r) s[r] = (r < nb) ? src[r * A.ld + li] : 0.0;
+      for (int r = 0; r < 7; ++r) s[r] = (r < nb) ? row(r) : 0.0;
       unpack_ompl<NJ>(A, s, st);
       if (WANT_JOINTS && A.planning_mode != MVK_MODE_ONLY_BASE) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) st[7 + j] = src[(nb + j) * A.ld + li];
+        for (int j = 0; j < NJ; ++j) st[7 + j] = row(nb + j);
       }
     }
   } else {
@@ -3943,7 +3946,7 @@ full_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevEx
   double st[7 + NJ];
   uint64_t edge;
   int step;
-  fetch_state<NJ, false, true>(A, li, st, edge, step);
+  fetch_state<NJ, false, true, true>(A, li, st, edge, step);
   double mind = INFINITY;
   if (model_wave) {
     Smem sm{(lds_double*)sm_cs, nullptr};
@@ -4387,7 +4390,7 @@ flag_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevEx
   double st[7 + NJ];
   uint64_t edge;
   int step;
-  fetch_state<NJ, EDGE, true>(A, gi, st, edge, step);
+  fetch_state<NJ, EDGE, true, !EDGE>(A, gi, st, edge, step);
   if (wv == 1) {
     Smem sm{(lds_double*)sm_cs, nullptr};
     StateOut o;
