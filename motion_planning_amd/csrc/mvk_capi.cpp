@@ -1679,7 +1679,18 @@ extern "C" int mvk_check_motion_batch_begin(mvk_ctx* c, const double* s1, const 
     a.layout = MVK_LAYOUT_OMPL;
     c->stats_valid = false;
     if (int rc = enter_stream(c, s)) return rc;
-    HIP_TRY(hipMemcpyAsync(dev, up, bytes, hipMemcpyHostToDevice, s));
+    if (n_edges == 1) {
+      // one edge (OMPL's checkMotion): its end states travel in the kernel arguments, nothing is copied up
+      a.inline_on = 1;
+      for (size_t r = 0; r < rows; ++r) { a.inline_state[r] = s1[r * ld]; a.inline_state2[r] = s2[r * ld]; }
+      a.s1 = a.s2 = nullptr;
+      a.nd = nullptr;
+      a.edge_off = nullptr;
+      a.edge_block = nullptr;
+      a.nd_uniform = hnd[0];
+    } else {
+      HIP_TRY(hipMemcpyAsync(dev, up, bytes, hipMemcpyHostToDevice, s));
+    }
     a.fused_seq = next_seq(c);
     a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
     {

@@ -188,9 +188,10 @@ struct EvalArgs {
   GridDev dgrid2;
   double dgrid2_radius;
   // a host call of ONE state carries its rows in the kernel arguments (flag_small_kernel, full_small_kernel): the
-  // kernel then starts without the dependent read of the pinned staging block over PCIe
+  // kernel then starts without the dependent read of the pinned staging block over PCIe (one edge: without the copy up)
   int32_t inline_on;
   double inline_state[MVK_MAX_STATE_DIM];
+  double inline_state2[MVK_MAX_STATE_DIM];  // a host call of ONE edge: its end states in inline_state / inline_state2
   GridDev fgrid;          // far grid (start == nullptr: none): complete nearest-candidate lists at any distance, inside its volume
   // C-space sweep (mvk_sweep_mask_dev): states are generated from the sample index, nothing is read
   int32_t sweep_on;

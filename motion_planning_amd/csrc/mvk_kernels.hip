@@ -2669,11 +2669,14 @@ DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t
     const double t = static_cast<double>(step) / static_cast<double>(nd_e);
     const bool last = step == nd_e;
     const int nb = (A.planning_mode == MVK_MODE_ONLY_JOINTS) ? 0 : (A.motion_type == MVK_SE2 ? 3 : 7);
+    const bool inl = INLINE && A.inline_on;  // (one edge: edge == 0)
+    auto row1 = [&](int r) -> double { return inl ? A.inline_state[r] : A.s1[r * A.ld + edge]; };
+    auto row2 = [&](int r) -> double { return inl ? A.inline_state2[r] : A.s2[r * A.ld + edge]; };
     double a[7], b[7], s[7];
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-      a[r] = (r < nb) ? A.s1[r * A.ld + edge] : 0.0;
-      b[r] = (r < nb) ? A.s2[r * A.ld + edge] : 0.0;
+      a[r] = (r < nb) ? row1(r) : 0.0;
+      b[r] = (r < nb) ? row2(r) : 0.0;
       s[r] = b[r];
     }
     if (!last && nb > 0) {
@@ -2691,7 +2694,7 @@ DEV void fetch_state(const EvalArgs& A, uint64_t li, double st[7 + NJ], uint64_t
     if (WANT_JOINTS && A.planning_mode != MVK_MODE_ONLY_BASE) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const double ja = A.s1[(nb + j) * A.ld + edge], jb = A.s2[(nb + j) * A.ld + edge];
+        const double ja = row1(nb + j), jb = row2(nb + j);
         st[7 + j] = last ? jb : fma(jb - ja, t, ja);
       }
     }
@@ -4390,7 +4393,7 @@ flag_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevEx
   double st[7 + NJ];
   uint64_t edge;
   int step;
-  fetch_state<NJ, EDGE, true, !EDGE>(A, gi, st, edge, step);
+  fetch_state<NJ, EDGE, true, true>(A, gi, st, edge, step);
   if (wv == 1) {
     Smem sm{(lds_double*)sm_cs, nullptr};
     StateOut o;
