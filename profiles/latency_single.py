@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """latency of single-state calls: mvk_is_valid (full kernel, distance + margin) vs a batch of one through the flag path.
-The first context of a process is slow on the call with every detail output (≈0.65 ms against ≈0.2 ms for later
-contexts of the same kind: c2k is therefore measured twice) when it follows the other two kinds of call; a context that
-only makes that call shows no such effect (0.25 ms, of which the kernel of one wave is 0.18 ms).  Not tracked down."""
+After an idle spell (the start of the process, or host-only work between two kinds of call) the GPU serves the first
+~50 ms of small launches several times slower -- its clocks ramp up -- which is why c2k is measured twice here and why
+bench.py's single_calls warms every kind of call for 0.2 s before timing it."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
