@@ -11,7 +11,8 @@ ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-planner --no-edges --no-legs 
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM" "GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -o p -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_$name.log 2>&1 || { echo "pass $pass failed"; tail -3 $OUT/pmc_$name.log; }
+  # (counters do not depend on the clocks: no pre-warm steps in the PMC passes, which serialise every dispatch)
+  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -o p -- python3 $ROOT/bench.py $ARGS --prewarm 0 > $OUT/pmc_$name.log 2>&1 || { echo "pass $pass failed"; tail -3 $OUT/pmc_$name.log; }
 done
 python3 $ROOT/profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
