@@ -461,7 +461,7 @@ def emit_line(obj):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--prewarm", type=int, default=1500,
                     help="untimed steps before the warm-up steps that bring the GPU out of its idle clocks (0: measure from cold)")
@@ -515,9 +515,10 @@ def main():
     eng.set_profiling(True)   # HIP events on the launch stream around each kernel of a call
     d_soa = torch.from_numpy(w.soa).to(dev)   # (c5: unused, the sweep reads no input)
     words = (n + 63) // 64
-    # Two sets of exchange buffers: the mask all-gather and the count all-reduce of step k run on RCCL's stream
-    # while the kernels of step k+1 fill the other set (collectives overlapped with compute).
-    n_slot = 2 if exchange else 1
+    # Four sets of exchange buffers: the mask all-gather and the count of step k run on the exchange stream while the
+    # kernels of steps k+1 .. k+3 fill the other sets (collectives overlapped with compute; the host waits for the
+    # exchange of step k-4 before it refills a set, which by then has long finished).
+    n_slot = 4 if exchange else 1
     d_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(n_slot)]
     d_alls = [torch.zeros(world * words, dtype=torch.int64, device=dev) for _ in range(n_slot)] if exchange else None
     d_cnts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n_slot)]
@@ -526,45 +527,51 @@ def main():
     sweep = args.workload == "c5"   # config 5: states generated in the kernel from the sample index, rank r sweeps [r*n, (r+1)*n)
     sweep_pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
 
+    main_stream = torch.cuda.current_stream()
+    side = torch.cuda.Stream(device=dev) if exchange else None   # the exchange's own stream: RCCL call + count kernel
+
     def run_batch(mask):
         if sweep:
-            eng.sweep_mask_dev(sweep_pose, rank * n, n, common.SEED0 + 5, mask)
+            eng.sweep_mask_dev(sweep_pose, rank * n, n, common.SEED0 + 5, mask, stream=main_stream)
         else:
-            eng.is_valid_mask_dev(d_soa, w.layout, mask)
+            eng.is_valid_mask_dev(d_soa, w.layout, mask, stream=main_stream)
 
-    main_stream = torch.cuda.current_stream()
-    side = torch.cuda.Stream(device=dev) if exchange else None   # the exchange's own stream: count kernel + RCCL calls
-    done = [None] * n_slot
+    # The host loop must stay well under the kernels' 0.14 ms per step, so the exchange is as few calls as it can
+    # be: one all-gather of the packed masks, then the valid count of the whole job taken from the gathered words by
+    # every rank itself (no second collective); events are made once, the side stream is current for the whole
+    # loop (the kernels are handed the main stream explicitly).
+    done = [torch.cuda.Event() for _ in range(n_slot)] if exchange else []
+    ready = [torch.cuda.Event() for _ in range(n_slot)] if exchange else []
+    used = [False] * n_slot
 
     def step(k, ev=None):
         slot = k % n_slot
-        if done[slot] is not None:    # this set's last exchange (step k-2) must be through before it is refilled
-            main_stream.wait_event(done[slot])   # (a stream dependency, the host does not block)
+        if exchange and used[slot]:   # this set's last exchange (step k-2) must be through before it is refilled
+            # a host wait, not a stream dependency: the exchange of two steps ago has long finished, and a wait in the
+            # launch stream is a barrier packet between this step's kernels and the last one's (a bubble of several us)
+            done[slot].synchronize()
         if ev:
-            ev[0].record()
+            ev[0].record(main_stream)
         run_batch(d_masks[slot])
         if ev:
-            ev[1].record()
+            ev[1].record(main_stream)
         if exchange:
-            ready = torch.cuda.Event()
-            ready.record(main_stream)
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                eng.mask_count_dev(d_masks[slot], n, d_cnts[slot])
-                works = (dist.all_gather_into_tensor(d_alls[slot], d_masks[slot], async_op=True),
-                         dist.all_reduce(d_cnts[slot], async_op=True))
-                for wk in works:
-                    wk.wait()
-                done[slot] = torch.cuda.Event()
-                done[slot].record(side)
+            ready[slot].record(main_stream)
+            side.wait_event(ready[slot])
+            dist.all_gather_into_tensor(d_alls[slot], d_masks[slot])   # (current stream = side; the host does not block)
+            eng.mask_count_dev(d_alls[slot], world * words * 64, d_cnts[slot], stream=side)
+            done[slot].record(side)
+            used[slot] = True
 
     def drain():
         for slot in range(n_slot):
-            if done[slot] is not None:
+            if exchange and used[slot]:
                 main_stream.wait_event(done[slot])
 
     eng.set_profiling(False)   # the library's event records are markers in the queue: not inside the timed region
     # (--prewarm untimed steps first: the GPU's clocks are up before the W warm-up steps and the K timed ones, see prewarm())
+    if exchange:
+        torch.cuda.set_stream(side)
     for k in range(args.prewarm + args.warmup):
         step(k)
     drain()
@@ -575,6 +582,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    t_issued = time.perf_counter() - t0   # host time to issue the K steps (diagnostic: a host-bound loop shows here)
     drain()
     torch.cuda.synchronize()
     if exchange:
@@ -601,21 +609,20 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the exchange on its own (reported separately): count kernel + mask all-gather + count
-        # all-reduce, back to back on the exchange stream, every rank
+        # the exchange on its own (reported separately): mask all-gather + count kernel over the
+        # gathered words, back to back on the exchange stream, every rank
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         dist.barrier()
-        with torch.cuda.stream(side):
-            e0.record(side)
-            for _ in range(10):
-                eng.mask_count_dev(d_masks[0], n, d_cnts[0])
-                dist.all_gather_into_tensor(d_alls[0], d_masks[0])
-                dist.all_reduce(d_cnts[0])
-            e1.record(side)
+        e0.record(side)
+        for _ in range(10):
+            dist.all_gather_into_tensor(d_alls[0], d_masks[0])
+            eng.mask_count_dev(d_alls[0], world * words * 64, d_cnts[0], stream=side)
+        e1.record(side)
         torch.cuda.synchronize()
         t = torch.tensor([e0.elapsed_time(e1) / 10], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         exchange_ms = float(t.item())
+        torch.cuda.set_stream(main_stream)
 
     if rank == 0:
         valid = int(sum(bin(int(x) & 0xFFFFFFFFFFFFFFFF).count("1") for x in d_mask.cpu().numpy()[:4096]))
@@ -645,8 +652,9 @@ def main():
         if exchange:
             last = (args.steps - 1) % n_slot
             out["valid_total_last_step"] = int(d_cnts[last].item())   # all-reduced over ranks (mvk_mask_count_dev + RCCL sum)
-            out["exchange"] = "per step: all-gather of the packed mask + all-reduce of the valid count, overlapped with the next step's kernels"
+            out["exchange"] = "per step: all-gather of the packed masks, valid count of the whole job from the gathered words on every rank; overlapped with the next step's kernels"
             out["exchange_ms"] = exchange_ms   # one exchange alone (max over ranks): what the overlap hides
+            out["host_issue_ms_per_step"] = t_issued / args.steps * 1e3   # rank 0's host loop: launches + exchange calls
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w)
         if not args.no_planner and world == 1:
