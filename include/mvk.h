@@ -96,8 +96,12 @@ typedef struct mvk_model {
   double seg_com[MVK_MAX_SEG][3]; /* centre of mass in the segment frame */
 
   int32_t rotor_seg[MVK_MAX_ROTOR];
-  double rotor_pos[MVK_MAX_ROTOR][3]; /* thrust-frame origin (gimbal centre) in its segment frame */
+  double rotor_pos[MVK_MAX_ROTOR][3]; /* gimbal roll-axis origin (rotor origin of a robot without gimbals) in its segment frame */
   double rotor_sigma[MVK_MAX_ROTOR];  /* +-1 spin direction */
+  /* gimballed rotors: the thrust-frame origin (what aerial_robot_model calls the rotor origin: statics, the
+   * roll/pitch position margin, the EDF pair test) sits rotor_roll_z along the z axis of the gimbal ROLL frame
+   * above rotor_pos.  DRAGON: 0.037, read off the reference's logs. */
+  double rotor_roll_z;
 
   double edf_offset_y; /* DRAGON dual EDFs sit at +-edf_offset_y of the gimbal-pitch frame */
   double edf_radius;
@@ -108,7 +112,7 @@ typedef struct mvk_model {
   double thrust_min, thrust_max;
   double fc_t_min_thre;  /* feasible-control torque distance threshold */
   double fc_rp_min_thre; /* feasible-control roll/pitch distance threshold */
-  double link_length;
+  double link_length;    /* informational: rp_position_margin is normalised by |rotor 2 - rotor 1| */
 
   int32_t prim_type[MVK_MAX_PRIM];  /* MVK_PRIM_* */
   int32_t prim_seg[MVK_MAX_PRIM];   /* segment the primitive rides on */

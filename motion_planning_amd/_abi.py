@@ -29,7 +29,7 @@ class Model(C.Structure):
         ("wrench_dof", i32), ("has_gimbal", i32),
         ("seg_axis", i32 * MAX_SEG), ("seg_joint", i32 * MAX_SEG), ("seg_link", i32 * MAX_SEG),
         ("seg_t", (d * 3) * MAX_SEG), ("seg_mass", d * MAX_SEG), ("seg_com", (d * 3) * MAX_SEG),
-        ("rotor_seg", i32 * MAX_ROTOR), ("rotor_pos", (d * 3) * MAX_ROTOR), ("rotor_sigma", d * MAX_ROTOR),
+        ("rotor_seg", i32 * MAX_ROTOR), ("rotor_pos", (d * 3) * MAX_ROTOR), ("rotor_sigma", d * MAX_ROTOR), ("rotor_roll_z", d),
         ("edf_offset_y", d), ("edf_radius", d), ("edf_max_tilt", d),
         ("gravity", d), ("m_f_rate", d), ("thrust_min", d), ("thrust_max", d),
         ("fc_t_min_thre", d), ("fc_rp_min_thre", d), ("link_length", d),

@@ -297,6 +297,7 @@ void derive_extras(const mvk_model* m, DevExtras* x) {
     f.fc_t_thre = static_cast<float>(m->fc_t_min_thre);
     f.fc_rp_thre = static_cast<float>(m->fc_rp_min_thre);
     f.edf_offset_y = static_cast<float>(m->edf_offset_y);
+    f.rotor_roll_z = static_cast<float>(m->rotor_roll_z);
     f.edf_two_r = static_cast<float>(2.0 * m->edf_radius);
     f.tan_edf_max_tilt = static_cast<float>(x->tan_edf_max_tilt);
     const double u = 5.9604645e-8;

@@ -57,10 +57,10 @@ struct ModelF32 {
   float rotor_ks[MVK_MAX_ROTOR];   // m_f_rate * sigma
   float inv_mass, weight;          // 1 / total mass, total mass * gravity
   float thrust_min, thrust_max, fc_t_thre, fc_rp_thre;
-  float edf_offset_y, edf_two_r, tan_edf_max_tilt;
+  float edf_offset_y, edf_two_r, tan_edf_max_tilt, rotor_roll_z;
   float err_p;   // position of a frame origin relative to the root, incl. the joints' cos/sin errors [m]
   float err_u;   // a component of a rotation matrix / thrust axis
-  float pad_[2];
+  float pad_[1];
 };
 
 struct DevExtras {

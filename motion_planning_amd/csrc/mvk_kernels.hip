@@ -599,9 +599,11 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
         // thrust axis = R * Rx(roll) * Ry(pitch) * z ;  EDFs at +-y of the pitch frame
         const double ux = sp, uy = -sr * cp, uz = cr * cp;
         const double ey = cr, ez = sr;  // Rx(roll) * y = (0, cr, sr)
+        const double hz = M->rotor_roll_z;  // thrust-frame origin: up the roll frame's z axis, Rx(roll) * z = (0, -sr, cr)
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           U[i][r] = fma(R[3 * r], ux, fma(R[3 * r + 1], uy, R[3 * r + 2] * uz));
+          P[i][r] = fma(hz, fma(R[3 * r + 2], cr, -R[3 * r + 1] * sr), P[i][r]);
           const double yw = fma(R[3 * r + 1], ey, R[3 * r + 2] * ez) * M->edf_offset_y;
           E[2 * i][r] = P[i][r] + yw;
           E[2 * i + 1][r] = P[i][r] - yw;
@@ -774,7 +776,9 @@ DEV void model_update(const EvalArgs& A, const mvk_model* __restrict__ M, const 
     sxx *= 1.0 / NL; sxy *= 1.0 / NL; syy *= 1.0 / NL;
     const double hd = 0.5 * (sxx - syy);
     const double lmin = 0.5 * (sxx + syy) - sqrt(fma(hd, hd, sxy * sxy));
-    out.rp_margin = sqrt(fmax(lmin, 0.0)) / M->link_length;
+    // normaliser |p_2 - p_1| (pinned by the reference's logs)
+    const double d0 = P[1][0] - P[0][0], d1 = P[1][1] - P[0][1], d2 = P[1][2] - P[0][2];
+    out.rp_margin = sqrt(fmax(lmin, 0.0)) / sqrt(fma(d0, d0, fma(d1, d1, d2 * d2)));
   }
 
   // stabilityCheck(): min slack over the active tests
@@ -921,6 +925,7 @@ DEV int model_update_f32(const EvalArgs& A, const DevExtras* __restrict__ X, con
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           U[i][r] = fmaf(R[3 * r], ux, fmaf(R[3 * r + 1], uy, R[3 * r + 2] * uz));
+          P[i][r] = fmaf(F.rotor_roll_z, fmaf(R[3 * r + 2], cr, -R[3 * r + 1] * sr), P[i][r]);  // thrust-frame origin
           const float yw = fmaf(R[3 * r + 1], ey, R[3 * r + 2] * ez) * F.edf_offset_y;
           E[2 * i][r] = P[i][r] + yw;
           E[2 * i + 1][r] = P[i][r] - yw;
@@ -946,7 +951,8 @@ DEV int model_update_f32(const EvalArgs& A, const DevExtras* __restrict__ X, con
   // three products.  Component-wise, because the rows of the wrench matrix differ in scale by orders of
   // magnitude (planar HYDRUS: the yaw-torque row is +-kappa).
   const float err_ua = bs * (S::kGimbal ? err_u : 2.0f * kF32U);
-  const float err_pc = bs * 2.0f * F.err_p;
+  // (gimbal models: the thrust-frame origin's offset up the roll frame's z axis rides on the solved roll)
+  const float err_pc = bs * (2.0f * F.err_p + (S::kGimbal ? 2.0f * fabsf(F.rotor_roll_z) * err_u : 0.0f));
   float V[NL][3], dVc[NL][3], Vm = 1.0f, dV = 0.0f;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
@@ -1148,7 +1154,7 @@ DEV int model_update_f32(const EvalArgs& A, const DevExtras* __restrict__ X, con
   }
   // ---- EDF overlap (gimbal models) ----
   if (S::kGimbal) {
-    const float dE = bs * (4.0f * F.err_p + 4.0f * F.edf_offset_y * err_u + 8.0f * kF32U * (Pm + 1.0f));
+    const float dE = bs * (4.0f * F.err_p + 4.0f * (F.edf_offset_y + fabsf(F.rotor_roll_z)) * err_u + 8.0f * kF32U * (Pm + 1.0f));
 #pragma unroll
     for (int a = 0; a < 2 * NL; ++a)
 #pragma unroll

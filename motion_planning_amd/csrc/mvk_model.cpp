@@ -12,6 +12,11 @@
 //       (squeeze_navigation/config/sampling_based_method/dragon_quad.yaml:43-58)
 //   collision link sets {link*, thrust*} / {link*, inter_joint*, gimbal*_{roll,pitch}_module}
 //       (sampling_based_method/config/{hydrus,dragon}/quad/moveit.srdf)
+// Pinned by the reference's planner logs (tests/golden/fit_dragon_model.py):
+//   DRAGON link 0.424 (pitch axis at its end), yaw axis 0.0515 behind the pitch axis, gimbal roll axis
+//   origin at mid-link, thrust-frame origin 0.037 up the roll frame's z axis: with these four numbers the
+//   rp_position_margin column of nine logs (2,761 states) is reproduced to the printed digits;
+//   HYDRUS rotor at mid-link: reproduces minimum_var 0.452857 @ state 200 of path_log/hydrus/hydrus_planning_log.txt.
 #include <cmath>
 #include <cstring>
 
@@ -110,6 +115,7 @@ extern "C" int mvk_model_dragon(int n_links, mvk_model* m) {
   m->thrust_max = 26.0;
   m->fc_t_min_thre = 0.0;   // off (fc_t is identically 0 with kappa = 0)
   m->fc_rp_min_thre = 2.0;
+  m->rotor_roll_z = 0.037;  // thrust-frame origin above the roll axis (pinned by the logs' margin column)
   m->edf_offset_y = 0.09;
   m->edf_radius = 0.065;
   m->edf_max_tilt = 0.1;  // dragon_quad.yaml:56
@@ -128,7 +134,7 @@ extern "C" int mvk_model_dragon(int n_links, mvk_model* m) {
       set3(m->seg_com[kj], 0.0, 0.0, 0.0);
       m->seg_axis[ks] = 2;  // yaw about z
       m->seg_joint[ks] = 2 * (i - 1) + 1;
-      set3(m->seg_t[ks], 0.015, 0.0, 0.0);
+      set3(m->seg_t[ks], 0.0515, 0.0, 0.0);  // pitch axis -> yaw axis (pinned by the logs' margin column)
     }
     m->rotor_seg[i] = ks;
     set3(m->rotor_pos[i], 0.5 * L, 0.0, 0.0);

@@ -71,10 +71,12 @@ def model_update(m, st):
             GR.append(Tr)
             GP.append(Tp)
             gim += [roll, pitch]
+            thr = (Tr @ np.array([0.0, 0.0, m.rotor_roll_z, 1.0]))[:3]   # thrust-frame origin, up the roll frame's z
         else:
             u = Fs[:3, 2]
-        O.append(o)
-        P.append(o - cog)
+            thr = o
+        O.append(thr)
+        P.append(thr - cog)
         U.append(u)
     P, U = np.array(P), np.array(U)
     sig = np.array(m.rotor_sigma[:N])
@@ -109,7 +111,7 @@ def model_update(m, st):
             tot += max(0.0, tp * fmax)
         fc_rp = min(fc_rp, tot)
     cov = np.cov(P[:, :2].T, bias=True)
-    rp_margin = np.sqrt(max(np.linalg.eigvalsh(cov)[0], 0.0)) / m.link_length
+    rp_margin = np.sqrt(max(np.linalg.eigvalsh(cov)[0], 0.0)) / np.linalg.norm(P[1] - P[0])   # normaliser pinned by the logs
     slacks = []
     if m.fc_rp_min_thre > 0:
         slacks.append(fc_rp - m.fc_rp_min_thre)
@@ -120,7 +122,7 @@ def model_update(m, st):
         E = []
         for i in range(N):
             for sgn in (+1, -1):
-                E.append((GP[i] @ np.array([0.0, sgn * m.edf_offset_y, 0.0, 1.0]))[:3])
+                E.append(O[i] + GP[i][:3, :3] @ np.array([0.0, sgn * m.edf_offset_y, 0.0]))
         for a_, b_ in itertools.combinations(range(2 * N), 2):
             if a_ // 2 == b_ // 2:
                 continue

@@ -385,12 +385,12 @@ void orc_eval_state(const mvk_model* m, const mvk_box* boxes, size_t n_boxes, co
    *    Gimballed rotors (Dragon::HydrusLikeRobotModel, App. C): roll/pitch are
    *    solved so the thrust axis is the CoG z axis, then FK is re-evaluated. */
   double P[MVK_MAX_ROTOR][3], U[MVK_MAX_ROTOR][3];
-  double gimR_roll[MVK_MAX_ROTOR][9], gimR_pitch[MVK_MAX_ROTOR][9], rot_o[MVK_MAX_ROTOR][3];
+  double gimR_roll[MVK_MAX_ROTOR][9], gimR_pitch[MVK_MAX_ROTOR][9], rot_o[MVK_MAX_ROTOR][3], thr_o[MVK_MAX_ROTOR][3];
   for (int i = 0; i < N; ++i) {
     int s = m->rotor_seg[i];
     double off[3];
     mat_vec(segR[s], m->rotor_pos[i], off);
-    for (int c = 0; c < 3; ++c) { rot_o[i][c] = segp[s][c] + off[c]; P[i][c] = rot_o[i][c] - cog[c]; }
+    for (int c = 0; c < 3; ++c) { rot_o[i][c] = thr_o[i][c] = segp[s][c] + off[c]; P[i][c] = rot_o[i][c] - cog[c]; }
     if (m->has_gimbal) {
       double zl[3] = {segR[s][6], segR[s][7], segR[s][8]}; /* CoG z axis seen from the link */
       double roll = atan2(-zl[1], zl[2]);
@@ -403,6 +403,12 @@ void orc_eval_state(const mvk_model* m, const mvk_box* boxes, size_t n_boxes, co
       o->gimbal[2 * i] = roll;
       o->gimbal[2 * i + 1] = pitch;
       U[i][0] = gimR_pitch[i][2]; U[i][1] = gimR_pitch[i][5]; U[i][2] = gimR_pitch[i][8];
+      /* the thrust frame's origin sits rotor_roll_z up the roll frame's z axis (pinned by the
+       * rp_position_margin column of the reference's DRAGON logs, tests/test_pathlog_statics.py) */
+      for (int c = 0; c < 3; ++c) {
+        thr_o[i][c] = rot_o[i][c] + m->rotor_roll_z * gimR_roll[i][3 * c + 2];
+        P[i][c] = thr_o[i][c] - cog[c];
+      }
     } else {
       U[i][0] = segR[s][2]; U[i][1] = segR[s][5]; U[i][2] = segR[s][8];
     }
@@ -507,8 +513,11 @@ void orc_eval_state(const mvk_model* m, const mvk_box* boxes, size_t n_boxes, co
   }
   o->fc_rp_min = fc_rp_min;
 
-  /* legacy roll/pitch position margin, logged as minimum_var
-   * (motion_planning.cpp:615-620): sqrt(lambda_min(Cov_xy(p_i))) / link_length */
+  /* legacy roll/pitch position margin, logged as minimum_var (motion_planning.cpp:615-620):
+   * sqrt(lambda_min(Cov_xy(p_i))) / |p_2 - p_1|, the normaliser being the distance between the first two
+   * rotor origins in the CoG frame.  PINNED: with it the DRAGON logs' per-state margins (2,761 states) and the
+   * HYDRUS log's minimum_var 0.452857 @ state 200 come out to the printed digits; link_length as the
+   * normaliser (this oracle before round 3) gives 0.354 where the logs print 0.5. */
   {
     double ax = 0, ay = 0, sxx = 0, sxy = 0, syy = 0;
     for (int i = 0; i < N; ++i) { ax += P[i][0]; ay += P[i][1]; }
@@ -520,7 +529,8 @@ void orc_eval_state(const mvk_model* m, const mvk_box* boxes, size_t n_boxes, co
     sxx /= N; sxy /= N; syy /= N;
     double hd = 0.5 * (sxx - syy);
     double lmin = 0.5 * (sxx + syy) - sqrt(hd * hd + sxy * sxy);
-    o->rp_position_margin = sqrt(lmin > 0.0 ? lmin : 0.0) / m->link_length;
+    double d01[3] = {P[1][0] - P[0][0], P[1][1] - P[0][1], P[1][2] - P[0][2]};
+    o->rp_position_margin = sqrt(lmin > 0.0 ? lmin : 0.0) / norm3(d01);
   }
 
   /* 6. stabilityCheck() (RobotModel / HydrusRobotModel / Dragon overlap, App. C) */
@@ -542,7 +552,7 @@ void orc_eval_state(const mvk_model* m, const mvk_box* boxes, size_t n_boxes, co
         for (int sgn = 0; sgn < 2; ++sgn) {
           double loc[3] = {0.0, sgn ? -m->edf_offset_y : m->edf_offset_y, 0.0}, w[3];
           mat_vec(gimR_pitch[i], loc, w);
-          for (int c = 0; c < 3; ++c) E[2 * i + sgn][c] = rot_o[i][c] + w[c] - cog[c];
+          for (int c = 0; c < 3; ++c) E[2 * i + sgn][c] = thr_o[i][c] + w[c] - cog[c];
         }
       for (int a = 0; a < 2 * N; ++a)
         for (int c2 = a + 1; c2 < 2 * N; ++c2) {

@@ -31,6 +31,11 @@ def crosscheck(w, ref, count=24):
         assert np.allclose(q["cog"], ref["cog"][:, i], rtol=1e-11, atol=1e-12)
         assert abs(q["fc_rp_min"] - ref["fc_rp_min"][i]) <= 1e-9 * max(1, abs(q["fc_rp_min"]))
         assert abs(q["fc_t_min"] - ref["fc_t_min"][i]) <= 1e-9 * max(1, abs(q["fc_t_min"]))
+        assert abs(q["rp_position_margin"] - ref["rp_position_margin"][i]) <= 1e-9
+        assert np.allclose(q["gimbal"], ref["gimbal"][:len(q["gimbal"]), i], atol=1e-10)
+        if np.isfinite(ref["margin"][i]) and q["cond"] < 1e6:
+            assert np.allclose(q["thrust"], ref["thrust"][:len(q["thrust"]), i], rtol=1e-7, atol=1e-8)
+            assert abs(q["margin"] - ref["margin"][i]) <= 1e-7 * max(1, abs(q["margin"]))
 
 
 def main():

@@ -34,8 +34,9 @@ def test_square_quad_closed_forms():
     assert np.allclose(r["cog"].ravel(), [0.3, 0.3, 0.0], atol=1e-14)
     # symmetric square => equal static thrusts = m g / N
     assert np.allclose(r["thrust"].ravel(), 4.0 * m.gravity / 4.0, rtol=1e-12)
-    # rotor offsets (+-0.3, 0), (0, +-0.3): covariance 0.045 I  =>  sqrt(0.045)/0.6
-    assert r["rp_position_margin"][0] == pytest.approx(math.sqrt(0.045) / 0.6, rel=1e-12)
+    # rotor offsets (+-0.3, 0), (0, +-0.3): covariance 0.045 I, neighbouring rotors 0.3 sqrt(2) apart
+    # => sqrt(0.045) / (0.3 sqrt 2) = 0.5, the value the reference's logs print for the square state
+    assert r["rp_position_margin"][0] == pytest.approx(0.5, rel=1e-12)
     # roll/pitch feasible-control distance: |v_i| = 0.3, one perpendicular arm contributes 0.3 * f_max
     assert r["fc_rp_min"][0] == pytest.approx(0.3 * m.thrust_max, rel=1e-12)
     assert r["min_dist"][0] == math.inf and r["flags"][0] == 1

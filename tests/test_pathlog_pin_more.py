@@ -161,12 +161,13 @@ def test_gpu_gimbal_angles_match_the_logged_ones(log):
     assert np.median(err) < 2e-6
 
 
-@pytest.mark.parametrize("log,gap,free", [(DRAGON_LOGS[0], 0.5, 366), (DRAGON_LOGS[1], 0.6, 254)])
+@pytest.mark.parametrize("log,gap,free", [(DRAGON_LOGS[0], 0.5, 366), (DRAGON_LOGS[1], 0.6, 256)])
 def test_logged_dragon_states_clear_the_recorded_gap(log, gap, free):
     """Fidelity check, not a parity pin (the robot's URDF is absent; this build's DRAGON is synthetic): the logs'
     *_param3.txt companions record the gap (gap_type 1, gap_x_width = gap_y_width = 0.5 / 0.6, gap_height 0.7), and the
     states the reference's planner accepted must not collide with those four boxes (sampling_based_method.cpp:114-150).
-    366 of 366 and 254 of 256 do; the two others touch by 3.2 mm.  The planning walls (ceiling, side walls) are not
+    366 of 366 and 256 of 256 do (with the chain geometry of rounds 1-2 -- yaw axis 0.015 behind the pitch axis --
+    two of them touched by 3.2 mm; the geometry pinned in round 3 by the logs' margin column, 0.0515, clears all).  The planning walls (ceiling, side walls) are not
     recorded in that revision's parameters and are left out; 83 % / 59 % of the states are stable under the synthetic
     masses, which says nothing either way."""
     S = load_states(log)
@@ -176,4 +177,3 @@ def test_logged_dragon_states_clear_the_recorded_gap(log, gap, free):
     assert len(boxes) == 4
     out = O.eval_batch(m, boxes, p, np.ascontiguousarray(S[:, :13].T), A.LAYOUT_POSE7)
     assert int((out["min_dist"] > 0).sum()) == free
-    assert out["min_dist"].min() > -0.004

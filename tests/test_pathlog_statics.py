@@ -1,0 +1,161 @@
+"""PIN (round 3): outputs of the absent aerial_robot_model / hydrus / dragon code that the reference's planner logs
+hold, used as data.  tests/golden/ref_dragon__*.txt are verbatim copies of files under
+aerial_motion/sampling_based_method/path_log/dragon/ (the prefix ref_dragon__ + the original name).
+
+What the logs print (motion_planning.cpp:615-631,639 and its older revisions):
+* nine logs, per state: pose 7 + 6 link joints [+ 8 gimbal angles] + getRollPitchPositionMargin() + max static thrust;
+* every log, in its header: minimum_var (the path minimum of that margin) and minimum_var_state_entry (its index) --
+  the statistics MotionPlanning::addState keeps (motion_planning.cpp:615-620).
+
+Pinned by them, to the printed digits, with the geometry tests/golden/fit_dragon_model.py reads off ONE log:
+* rp_position_margin (formula incl. its normaliser |p_2 - p_1|, DRAGON chain geometry, thrust-frame origin): 2,761 states;
+* the gimbal solve on every log that has gimbal columns: 14 logs, 4,198 states x 8 angles;
+* the addState statistics (minimum + argmin) on 17 logs, HYDRUS' 0.452857 @ 200 included.
+NOT pinned: the max-static-thrust column (needs the URDF's inertial tags; fit_dragon_model.py --thrust prints the
+residuals of the formulations tried) -- test_static_thrust_column_is_not_reproduced keeps that statement honest.
+"""
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+import motion_planning_amd as mp
+import oracle_lib as O
+from motion_planning_amd import _abi as A
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ALL = sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLD, "ref_dragon_*.txt")))
+
+
+def load(name):
+    rows, hdr = [], {}
+    for line in open(os.path.join(GOLD, name)):
+        if line.startswith("state") and not line.startswith("states"):
+            rows.append([float(x) for x in line.split()[1:]])
+        else:
+            m = re.match(r"(minimum_var|minimum_var_state_entry)\s*:\s*([-0-9.e+]+)", line)
+            if m:
+                hdr[m.group(1)] = float(m.group(2))
+    return np.array(rows), hdr
+
+
+STATICS = [n for n in ALL if load(n)[0].shape[1] in (15, 23)]      # ... + margin + max thrust
+GIMBAL = [n for n in ALL if load(n)[0].shape[1] in (21, 23)]       # ... + 8 gimbal angles ...
+
+
+def dragon():
+    m = mp.make_model("dragon", 4)
+    return m, mp.default_params(m, A.MODE_JOINTS_AND_BASE, A.SE3)
+
+
+def oracle_eval(S):
+    m, p = dragon()
+    return O.eval_batch(m, np.zeros((0, 10)), p, np.ascontiguousarray(S[:, :13].T), A.LAYOUT_POSE7, threads=4)
+
+
+def test_the_fixture_set_is_what_the_docstring_says():
+    assert len(STATICS) == 9 and sum(len(load(n)[0]) for n in STATICS) == 2761
+    assert len(GIMBAL) == 14 and sum(len(load(n)[0]) for n in GIMBAL) == 4198
+    assert len(ALL) == 16
+
+
+# the logs print 6 significant digits of a value <= 0.52 (half a unit: 5e-7) computed from 13 inputs that were
+# themselves printed to 6 digits (the margin's sensitivity to them is below one)
+MARGIN_TOL = 4e-6
+
+
+@pytest.mark.parametrize("log", STATICS)
+def test_oracle_rp_position_margin_matches_the_logged_column(log):
+    S, _ = load(log)
+    got = oracle_eval(S)["rp_position_margin"]
+    err = np.abs(got - S[:, -2])
+    assert err.max() < MARGIN_TOL, (err.max(), int(err.argmax()))
+    assert np.sqrt(np.mean(err ** 2)) < 1e-6
+    # the level square (every log starts there) prints exactly 0.5: link_length as the normaliser gives 0.354
+    assert S[0, -2] == 0.5 and abs(got[0] - 0.5) < 1e-6
+
+
+@pytest.mark.parametrize("log", GIMBAL)
+def test_oracle_gimbal_angles_match_every_log_that_prints_them(log):
+    S, _ = load(log)
+    err = np.abs(oracle_eval(S)["gimbal"].T - S[:, 13:21])
+    assert err.max() < 6e-5 and np.median(err) < 2e-6, (err.max(), np.median(err))
+
+
+# file -> the header's index does not follow the states (hand-edited "best" file: states cut out after the run)
+EDITED = {"ref_dragon_log_gap_0p5_wall3_best.txt"}
+
+
+@pytest.mark.parametrize("log", ALL)
+def test_oracle_addstate_minimum_matches_the_log_header(log):
+    """MotionPlanning::addState keeps min rp_position_margin and its state index; savePath prints both"""
+    S, hdr = load(log)
+    got = oracle_eval(S)["rp_position_margin"]
+    assert abs(got.min() - hdr["minimum_var"]) < MARGIN_TOL, (got.min(), hdr)
+    if log not in EDITED:
+        assert int(got.argmin()) == int(hdr["minimum_var_state_entry"])
+
+
+def hydrus_log_states():
+    S, hdr = load("ref_hydrus_planning_log.txt")
+    assert S.shape == (235, 10) and hdr == {"minimum_var": 0.452857, "minimum_var_state_entry": 200.0}
+    return S
+
+
+def test_oracle_reproduces_the_hydrus_minimum_var():
+    """path_log/hydrus/hydrus_planning_log.txt:7-8 -- SURVEY 7.2-5 called this number not reproducible (0.345 with the
+    link length as the normaliser); with |p_2 - p_1| and the rotor at mid-link it is 0.452858 at state 200."""
+    S = hydrus_log_states()
+    m = mp.make_model("hydrus", 4)
+    p = mp.default_params(m, A.MODE_JOINTS_AND_BASE, A.SE2)
+    got = O.eval_batch(m, np.zeros((0, 10)), p, np.ascontiguousarray(S.T), A.LAYOUT_POSE7)["rp_position_margin"]
+    assert abs(got.min() - 0.452857) < 2e-6 and int(got.argmin()) == 200
+
+
+def test_static_thrust_column_is_not_reproduced():
+    """Honesty guard: the synthetic masses do NOT reproduce the logged max static thrust.  If a
+    later mass model closes this gap, this test fails and the claim in DESIGN.md has to be rewritten."""
+    S, _ = load(STATICS[3])
+    thr = np.nanmax(oracle_eval(S)["thrust"], axis=0)
+    rel = np.abs(thr - S[:, -1]) / S[:, -1]
+    assert 0.01 < rel.max() < 0.25
+
+
+# ---- the product on the same data -------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_gpu_margin_gimbal_and_path_minimum_match_the_logs():
+    m, p = dragon()
+    eng = mp.Engine(m, mp.vertical_gap_scene(0.5, 0.5, 0.7), p)
+    try:
+        for log in sorted(set(STATICS + GIMBAL)):
+            S, hdr = load(log)
+            got = eng.eval_batch(np.ascontiguousarray(S[:, :13].T), A.LAYOUT_POSE7)
+            if log in STATICS:
+                err = np.abs(got["rp_position_margin"] - S[:, -2])
+                assert err.max() < MARGIN_TOL, (log, err.max())
+            if log in GIMBAL:
+                err = np.abs(got["gimbal"].T - S[:, 13:21])
+                assert err.max() < 6e-5, (log, err.max())
+            # mvk_reduce_stats = the addState statistics, reduced on the device
+            st = eng.reduce_stats()
+            assert abs(st["min_rp_position_margin"] - hdr["minimum_var"]) < MARGIN_TOL, (log, st["min_rp_position_margin"], hdr)
+            assert int(st["min_rp_position_margin_index"]) == int(hdr["minimum_var_state_entry"]), log
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_hydrus_minimum_var():
+    S = hydrus_log_states()
+    m = mp.make_model("hydrus", 4)
+    p = mp.default_params(m, A.MODE_JOINTS_AND_BASE, A.SE2)
+    eng = mp.Engine(m, mp.horizontal_gap_scene(), p)
+    try:
+        got = eng.eval_batch(np.ascontiguousarray(S.T), A.LAYOUT_POSE7)
+        st = eng.reduce_stats()
+    finally:
+        eng.close()
+    assert abs(got["rp_position_margin"].min() - 0.452857) < 2e-6
+    assert abs(st["min_rp_position_margin"] - 0.452857) < 2e-6 and int(st["min_rp_position_margin_index"]) == 200
