@@ -306,7 +306,12 @@ int mvk_is_valid_mask_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld
  *   - n is limited to MVK_NOALLOC_MAX_STATES per call (MVK_ERR_CAPACITY beyond, nothing is launched);
  *   - every ctx on one GPU shares that array: calls of this entry point that overlap on one GPU
  *     (two streams, two ctxs, two threads) race.  Issue them one after another in stream order.
- * Same arguments, same result bits as mvk_is_valid_mask_dev (tests/test_zz_no_alloc.py). */
+ * Same arguments as mvk_is_valid_mask_dev and the same result bits as its fp64 path: this entry point always
+ * computes in fp64, whatever mvk_set_flag_precision selected (tests/test_zz_no_alloc.py).
+ * Under graph capture (`stream` is capturing): the call waits ON THE HOST for the ctx's previous call on any
+ * other stream, captures a memset node and its kernels, and records nothing about itself in the ctx, so
+ * launches of the graph are the caller's to keep in order with other calls on the ctx and with other users of
+ * the array (tests/test_zz_no_alloc.py::test_noalloc_call_captured_into_a_graph_replays). */
 #define MVK_NOALLOC_MAX_STATES 65536
 int mvk_is_valid_mask_noalloc_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout,
                                   uint64_t* d_mask, void* stream);

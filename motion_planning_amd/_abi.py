@@ -213,3 +213,24 @@ def load():
         raise RuntimeError("ctypes struct layout differs from the C ABI")
     _LIB = lib
     return lib
+
+
+_HIP = None
+
+
+def hip_runtime():
+    """libamdhip64 through ctypes (tests: raw streams outside torch's pool)"""
+    global _HIP
+    if _HIP is None:
+        for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+            try:
+                _HIP = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if _HIP is None:
+            raise RuntimeError("libamdhip64.so not found")
+        _HIP.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        _HIP.hipStreamSynchronize.argtypes = [C.c_void_p]
+        _HIP.hipStreamDestroy.argtypes = [C.c_void_p]
+    return _HIP

@@ -556,25 +556,68 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
 
 // Ordering of the calls that use the ctx's scratch buffers (see mvk_ctx::order_ev): a call on a stream other than
 // the last one's first makes its stream wait for the last call's work; every call leaves its own mark behind.
+//
+// The last call's stream may be the CALLER's (every _dev entry point takes one), and by the time the next call
+// arrives it may be idle, destroyed, or under graph capture.  Nothing is recorded on it without looking first:
+//   hipStreamQuery == hipSuccess      nothing of ours is left on it: no dependency to add
+//   hipStreamQuery == hipErrorNotReady  alive and busy: record the mark there, make the new stream wait (the lazy
+//                                     form: calls that stay on one stream never pay for an event between launches)
+//   capturing                         an event cannot be recorded outside the capture: the call is refused with a
+//                                     message, the ctx's state is untouched (it works again once the capture ended)
+//   anything else (handle destroyed)  its work may still be draining: one device-wide wait, then carry on
+// and whatever happens the ctx is never left pointing at a stream it cannot use.
+bool stream_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
+// host wait for whatever the ctx last enqueued on `order_stream`, without trusting the handle
+int drain_order_stream(mvk_ctx* c) {
+  if (!c->order_armed) return MVK_OK;
+  if (c->order_stream != c->stream && stream_capturing(c->order_stream))
+    return fail(MVK_ERR_INVALID_ARG, "the stream of the previous call on this ctx is under graph capture: end the capture first");
+  const hipError_t q = c->order_stream == c->stream ? hipErrorNotReady : hipStreamQuery(c->order_stream);
+  if (q == hipErrorNotReady) {
+    if (hipStreamSynchronize(c->order_stream) == hipSuccess) { c->order_armed = false; return MVK_OK; }
+  } else if (q == hipSuccess) {
+    c->order_armed = false;
+    return MVK_OK;
+  }
+  (void)hipGetLastError();  // stale handle: the stream's work may still be running
+  c->order_armed = false;
+  HIP_TRY(hipDeviceSynchronize());
+  return MVK_OK;
+}
 int enter_stream(mvk_ctx* c, hipStream_t s) {
-  if (c->order_armed && s != c->order_stream) {
-    // lazily: the mark is recorded on the previous call's stream only now, when a call on another stream needs
-    // it (it then covers everything that stream was given so far); calls that stay on one stream pay nothing
-    HIP_TRY(hipEventRecord(c->order_ev, c->order_stream));
-    HIP_TRY(hipStreamWaitEvent(s, c->order_ev, 0));
+  if (!c->order_armed || s == c->order_stream) return MVK_OK;
+  if (stream_capturing(s)) {
+    // the new call is being captured: a wait on an event recorded outside the capture would either fail or drop
+    // out of the graph, so the dependency on the earlier call is resolved here, on the host
+    return drain_order_stream(c);
+  }
+  if (c->order_stream != c->stream) {  // a caller's stream: look before touching it
+    if (stream_capturing(c->order_stream))
+      return fail(MVK_ERR_INVALID_ARG, "the stream of the previous call on this ctx is under graph capture: end the capture first");
+    const hipError_t q = hipStreamQuery(c->order_stream);
+    if (q == hipSuccess) { c->order_armed = false; return MVK_OK; }
+    if (q != hipErrorNotReady) { (void)hipGetLastError(); return drain_order_stream(c); }
+  }
+  if (hipEventRecord(c->order_ev, c->order_stream) != hipSuccess || hipStreamWaitEvent(s, c->order_ev, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return drain_order_stream(c);
   }
   return MVK_OK;
 }
 int leave_stream(mvk_ctx* c, hipStream_t s) {
+  // a call captured into a graph ran nothing: there is no work of it to order later calls behind (the graph's
+  // launches are the caller's to order against other users of the ctx, mvk.h)
+  if (s != c->stream && stream_capturing(s)) return MVK_OK;
   c->order_stream = s;
   c->order_armed = true;
   return MVK_OK;
 }
 // host wait for the last call on the ctx, whatever stream it went to
-int wait_last_call(mvk_ctx* c) {
-  if (c->order_armed) HIP_TRY(hipStreamSynchronize(c->order_stream));
-  return MVK_OK;
-}
+int wait_last_call(mvk_ctx* c) { return drain_order_stream(c); }
 
 // ---- small host batches: one launch, no copies (fused_kernel) --------------------------------------------------
 // eligible: flag path in fp64, at most kFusedMaxBlocks blocks of lanes (all resident at once)
@@ -879,7 +922,7 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
 extern "C" void mvk_destroy(mvk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->order_armed) (void)hipStreamSynchronize(c->order_stream);  // the last call may be on a caller's stream
+  (void)drain_order_stream(c);  // the last call may be on a caller's stream (possibly gone by now)
   if (c->stream) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
@@ -1059,8 +1102,10 @@ extern "C" int mvk_is_valid_mask_noalloc_dev(mvk_ctx* c, const double* d_soa, si
   if (int rc = enter_stream(c, s)) return rc;
   // the array keeps the last call's contents (any ctx of this GPU): the counters must start at zero
   HIP_TRY(hipMemsetAsync(base, 0, kStaticCounterSetBytes, s));
-  const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s, c->profiling ? c->ev : nullptr);
-  c->timed = c->profiling;
+  // (under graph capture the profiling events would be recorded into the graph: left out)
+  const bool timed = c->profiling && !stream_capturing(s);
+  const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s, timed ? c->ev : nullptr);
+  c->timed = timed;
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
   return leave_stream(c, s);
 }

@@ -60,3 +60,78 @@ def test_noalloc_entry_point_equals_the_allocating_one():
     assert int(m.abs().sum()) == 0
     eng.close()
     eng3.close()
+
+
+def test_noalloc_call_captured_into_a_graph_replays():
+    """the entry point is documented for code under HIP graph capture.  A host call (the ctx's own stream)
+    comes first, then the noalloc call is captured on another stream and the graph is launched twice with different
+    inputs in the same device buffers: same masks as the allocating entry point, and the ctx still works afterwards
+    (the ordering state must not end up pointing into the capture)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 20000 + 13
+    w = common.config2k(n=2 * n)
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    words = (n + 63) // 64
+    d_in = torch.from_numpy(np.ascontiguousarray(w.soa[:, :n])).to(dev)
+    d_mask = torch.zeros(words, dtype=torch.int64, device=dev)
+    ref = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(2)]
+    for k in range(2):
+        eng.is_valid_mask_dev(torch.from_numpy(np.ascontiguousarray(w.soa[:, k * n:(k + 1) * n])).to(dev), w.layout, ref[k])
+    host_flags = eng.is_valid_batch(w.soa[:, :512], w.layout)["flags"]      # a host call: the ctx's own stream
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        g.capture_begin(capture_error_mode="thread_local")
+        eng.is_valid_mask_noalloc_dev(d_in, w.layout, d_mask, stream=side)
+        g.capture_end()
+    assert int(d_mask.abs().sum()) == 0                # captured, not run
+    for k in range(2):
+        d_in.copy_(torch.from_numpy(np.ascontiguousarray(w.soa[:, k * n:(k + 1) * n])))
+        d_mask.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(d_mask, ref[k]), k
+    # the ctx is not wedged: host and device calls on other streams still work and agree
+    assert np.array_equal(eng.is_valid_batch(w.soa[:, :512], w.layout)["flags"], host_flags)
+    again = torch.zeros(words, dtype=torch.int64, device=dev)
+    eng.is_valid_mask_dev(d_in, w.layout, again)
+    torch.cuda.synchronize()
+    assert torch.equal(again, ref[1])
+    eng.close()
+
+
+def test_ctx_survives_a_destroyed_caller_stream():
+    """the previous call's stream belongs to the caller and may be gone when the next call arrives; the
+    ordering logic must look before it records anything there, and the ctx must keep working."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 4096
+    w = common.config2(n=n)
+    eng = mp.Engine(w.model, w.boxes, w.params)
+    d = torch.from_numpy(w.soa).to(dev)
+    words = n // 64
+    ref = torch.zeros(words, dtype=torch.int64, device=dev)
+    eng.is_valid_mask_dev(d, w.layout, ref)
+    torch.cuda.synchronize()
+    hip = A.hip_runtime()
+    s = A.C.c_void_p()
+    assert hip.hipStreamCreate(A.C.byref(s)) == 0
+    got = torch.zeros(words, dtype=torch.int64, device=dev)
+
+    class _S:   # the shape Engine._stream expects
+        cuda_stream = s.value
+    eng.is_valid_mask_dev(d, w.layout, got, stream=_S)
+    assert hip.hipStreamSynchronize(s) == 0
+    assert hip.hipStreamDestroy(s) == 0
+    assert torch.equal(got, ref)
+    for _ in range(3):   # next calls: another stream, then the host path
+        got.zero_()
+        eng.is_valid_mask_dev(d, w.layout, got)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+        bits = np.unpackbits(ref.cpu().numpy().view(np.uint8), bitorder="little")[:256]
+        assert np.array_equal(eng.is_valid_batch(w.soa[:, :256], w.layout)["flags"], bits)
+    eng.close()
