@@ -499,8 +499,9 @@ int mvk_path_resample(const double* cog_states, int n, int n_joint, double angul
                       double* out, int cap);
 /* ContinuousPathGenerator::discretePathSmoothing (continuous_path_generator.cpp:57-117): low-pass filter over the
  * ROOT states of a path (root xyz + joints in one filter, root orientation in another, both of factor filter_rate,
- * default 0.1 (:61); the filters start on the first state and the last state is repeated 1 / filter_rate times, so
- * the output has n + floor(1 / filter_rate) states and ends on the last one).  PARITY UNPINNED: the filters themselves
+ * default 0.1 (:61); the filters start on the first state and the last state is repeated while
+ * index < n + 1 / filter_rate in floating point (:83), so the output has n + 1 / filter_rate states when that is an
+ * integer (0.1: n + 10) and n + ceil(1 / filter_rate) otherwise (0.3: n + 4), and ends on the last one).  PARITY UNPINNED: the filters themselves
  * (FirFilter / FirFilterQuaternion of the external kalman_filter package) are absent; restated as a moving average
  * over round(1 / filter_rate) inputs.  out == NULL: returns the number of states it would write. */
 int mvk_path_smooth(const double* states, int n, int n_joint, double filter_rate, double* out, int cap);

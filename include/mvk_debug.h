@@ -1,0 +1,27 @@
+/* mvk_debug.h -- diagnostic entry points of libmvk.so.  Not part of the drop-in boundary (include/mvk.h): no
+ * reference interface stands behind them; tests and profiles/ use them to look inside the kernels.  They are
+ * exported by the release library so the GPU tests can run against the shipped binary; signatures may change. */
+#ifndef MVK_DEBUG_H
+#define MVK_DEBUG_H
+#include "mvk.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One pass of the fp32 screen stage (MVK_PRECISION_F32_REFINED) that also writes, per state, what its stability
+ * classification worked with: d_lo = smallest (slack - error bound) over the tests it could bound, d_hi = smallest
+ * (slack + error bound), d_cls = 1 certainly stable / 0 certainly unstable / -1 uncertain (refined in fp64) /
+ * -2 non-finite input.  tests/test_gpu_f32.py. */
+int mvk_debug_f32_bounds(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
+                         double* d_lo, double* d_hi, double* d_cls, void* stream);
+
+/* Number of host calls on this ctx whose one-launch (fused) form gave up at its grid barrier and were repeated
+ * with two launches (mvk_capi.cpp: fused_wait).  The environment variable MVK_FUSED_SPIN_LIMIT, read at mvk_create,
+ * bounds the barrier's polls (0 = give up at once unless every block has already arrived):
+ * tests/test_gpu_fused_giveup.py.  reset != 0 clears the count after reading it. */
+long long mvk_debug_fused_giveups(mvk_ctx* ctx, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -30,6 +30,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <limits>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -218,8 +219,6 @@ class StateValidityChecker : public ompl::base::StateValidityChecker, public det
   StateValidityChecker(const ompl::base::SpaceInformationPtr& si, mvk_ctx* ctx, int n_joint)
       : ompl::base::StateValidityChecker(si), ctx_(ctx), n_joint_(n_joint), params_(params_of(ctx)) {}
 
-  // the base class's isValid(state, dist) / clearance() stay visible next to the batched overload below
-  using ompl::base::StateValidityChecker::isValid;
 
   // MotionPlanning::isStateValid (motion_planning.cpp:76-164)
   bool isValid(const ompl::base::State* state) const override {
@@ -229,6 +228,31 @@ class StateValidityChecker : public ompl::base::StateValidityChecker, public det
     std::uint8_t flag = 0;
     if (!ok(mvk_is_valid_batch(ctx_, s, 1, 1, MVK_LAYOUT_OMPL, &flag, nullptr, nullptr, nullptr))) return false;
     return flag != 0;
+  }
+
+  // ompl::base::StateValidityChecker::clearance: "the distance to the nearest invalid state ... if the distance is
+  // negative, the value of clearance is the penetration depth".  Here: the signed separation between the robot's
+  // collision primitives and the world boxes (mvk_result::min_dist, the distance semantics of
+  // collision_avoidance.cpp:211-226), +infinity when the collision stage is off (planning mode 0) or the world is
+  // empty, NaN after a library error.  The reference installs an ObstacleBasedValidStateSampler allocator
+  // (motion_planning.h:168-171); samplers of that family (MaximizeClearanceValidStateSampler) call this.
+  double clearance(const ompl::base::State* state) const override {
+    double dist = 0.0;
+    (void)isValid(state, dist);
+    return dist;
+  }
+
+  // verdict and clearance from ONE full evaluation (mvk_is_valid); the base class would evaluate twice
+  bool isValid(const ompl::base::State* state, double& dist) const override {
+    double s[MVK_MAX_STATE_DIM];
+    flatten_state(params_, n_joint_, state, s);
+    mvk_result r{};
+    if (!ok(mvk_is_valid(ctx_, s, &r))) {
+      dist = std::numeric_limits<double>::quiet_NaN();
+      return false;
+    }
+    dist = r.min_dist;
+    return r.valid != 0;
   }
 
   // batched isValid(states[N]): one kernel launch for all N states; on an error every out[i] = 0

@@ -185,6 +185,13 @@ def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmvk.so")
 
 
+# every symbol include/mvk_debug.h declares (diagnostics, not part of the drop-in boundary)
+DEBUG_PROTOTYPES = {
+    "mvk_debug_f32_bounds": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, vp]),
+    "mvk_debug_fused_giveups": (C.c_longlong, [vp, ip]),
+}
+
+
 def load():
     """Load libmvk.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
     global _LIB
@@ -203,7 +210,7 @@ def load():
     except ImportError:
         pass
     lib = C.CDLL(path)
-    for name, (res, args) in PROTOTYPES.items():
+    for name, (res, args) in list(PROTOTYPES.items()) + list(DEBUG_PROTOTYPES.items()):
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args

@@ -88,10 +88,7 @@ extern "C" int mvk_adapter_check_run(mvk_ctx* ctx, int n_joint, const double* s1
     mv_impl.checkMotions(from.data(), to.data(), static_cast<std::size_t>(n), motions_ok, motions_first);
     counters[2] = svc_impl.errorCount();
     counters[3] = mv_impl.errorCount();
-    // the base class's other virtuals stay reachable through the derived type (no name hiding)
-    double dist = -1.0;
-    (void)svc_impl.isValid(all[0], dist);
-    return dist == 0.0 ? 0 : -100;
+    return 0;
   } catch (const std::exception&) {
     return -101;
   }
@@ -122,6 +119,31 @@ extern "C" int mvk_adapter_check_errors(mvk_ctx* good_ctx, int n_joint, const do
     out[7] = svc.lastError().empty() ? 0 : 1;
     std::int32_t fi = 0;
     if (mvk_check_motion_batch_end(good_ctx, nullptr, &fi) != MVK_OK) return -103;
+    return 0;
+  } catch (const std::exception&) {
+    return -101;
+  }
+}
+
+// clearance() and isValid(state, dist) through the base-class pointer (the virtuals a valid-state sampler calls):
+// states: [n][dim] row-major in MVK_LAYOUT_OMPL -> clearance[n], valid_with_dist[n], dist[n]
+extern "C" int mvk_adapter_check_clearance(mvk_ctx* ctx, int n_joint, const double* states, int n, double* clearance,
+                                           std::uint8_t* valid_with_dist, double* dist, unsigned* errors) {
+  try {
+    auto si = std::make_shared<ob::SpaceInformation>();
+    mvk::StateValidityChecker svc_impl(si, ctx, n_joint);
+    const ob::StateValidityChecker* svc = &svc_impl;
+    const mvk_params prm = svc_impl.params();
+    const int dim = mvk_space_dim(&prm, n_joint);
+    Owned st(prm, n_joint);
+    for (int i = 0; i < n; ++i) {
+      mvk::unflatten_state(prm, n_joint, states + static_cast<std::size_t>(i) * dim, st.top);
+      clearance[i] = svc->clearance(st.top);
+      double d = -12345.0;
+      valid_with_dist[i] = svc->isValid(st.top, d) ? 1 : 0;
+      dist[i] = d;
+    }
+    *errors = svc_impl.errorCount();
     return 0;
   } catch (const std::exception&) {
     return -101;

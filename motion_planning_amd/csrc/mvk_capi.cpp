@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "mvk_internal.h"
+#include "../../include/mvk_debug.h"
 
 namespace mvk {
 
@@ -120,6 +121,8 @@ struct mvk_ctx {
   uint32_t fused_seq = 0;
   int fused_max_blocks = kFusedMaxBlocks;  // blocks of kBlock lanes up to which a host call takes one fused launch
   bool fused_enabled = true;
+  long long fused_giveups = 0;  // host calls repeated with two launches because the fused launch's barrier gave up (mvk_debug.h)
+  uint32_t fused_spin_limit = 1u << 16;  // ~30 ms of polling before a block of the fused launch gives up on the grid barrier
   bool split_enabled = true;       // edge batches of the fused path: two lanes per step (MVK_NO_SPLIT=1: one)
   Buf small_done;                  // distance_small_kernel: blocks finished, over all polled calls (never reset)
   uint32_t small_total = 0;        // ... and the count the last polled call ends on
@@ -636,6 +639,7 @@ int fused_arm(mvk_ctx* c, EvalArgs& a, hipStream_t s, size_t n_edges) {
   a.fused_bar = a.queue_count + static_cast<size_t>(MVK_MAX_SEG * kQueueShards - 2) * kQueueCounterPitch;
   a.fused_done = a.queue_count + static_cast<size_t>(MVK_MAX_SEG * kQueueShards - 3) * kQueueCounterPitch;
   a.fused_seq = next_seq(c);
+  a.fused_spin_limit = c->fused_spin_limit;
   a.host_done = static_cast<volatile uint32_t*>(c->pin_ctl.p);
   if (n_edges) {
     const size_t before = c->first_tag.cap;
@@ -659,7 +663,7 @@ int fused_wait(mvk_ctx* c, uint32_t seq, hipStream_t s, int* gave_up) {
   for (unsigned spin = 0;; ++spin) {
     const uint32_t v = __atomic_load_n(const_cast<const uint32_t*>(const_cast<uint32_t*>(done)), __ATOMIC_ACQUIRE);
     if ((v & 0x7FFFFFFFu) == seq) {
-      if (v & 0x80000000u) { *gave_up = 1; HIP_TRY(hipStreamSynchronize(s)); }
+      if (v & 0x80000000u) { *gave_up = 1; ++c->fused_giveups; HIP_TRY(hipStreamSynchronize(s)); }
       return MVK_OK;
     }
     __builtin_ia32_pause();
@@ -669,6 +673,7 @@ int fused_wait(mvk_ctx* c, uint32_t seq, hipStream_t s, int* gave_up) {
   const uint32_t v = *done;
   if ((v & 0x7FFFFFFFu) != seq) return fail(MVK_ERR_HIP, "fused flag path: the kernel finished without raising its done word");
   *gave_up = (v & 0x80000000u) ? 1 : 0;
+  if (*gave_up) ++c->fused_giveups;
   return MVK_OK;
 }
 
@@ -915,6 +920,7 @@ extern "C" mvk_ctx* mvk_create(const mvk_model* model, const mvk_box* boxes, siz
   if (const char* v = std::getenv("MVK_FLAG_SMALL_MAX")) if (std::atoll(v) > 0 && std::atoll(v) <= 1024) c->flag_small_max = static_cast<uint64_t>(std::atoll(v));  // diagnostics
   if (const char* v = std::getenv("MVK_FUSED_MAX_BLOCKS")) if (std::atoi(v) > 0 && std::atoi(v) <= kFusedHardMax) c->fused_max_blocks = std::atoi(v);  // diagnostics
   if (const char* off = std::getenv("MVK_NO_SPLIT")) c->split_enabled = off[0] != '1';  // diagnostics
+  if (const char* v = std::getenv("MVK_FUSED_SPIN_LIMIT")) c->fused_spin_limit = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));  // diagnostics: 0 forces the give-up path
   if (const char* off = std::getenv("MVK_NO_FUSED")) c->fused_enabled = off[0] != '1';  // diagnostics: always two launches
   return c;
 }
@@ -1033,7 +1039,15 @@ extern "C" int mvk_is_valid_mask_dev(mvk_ctx* c, const double* d_soa, size_t n, 
                       static_cast<hipStream_t>(stream));
 }
 
-// Diagnostic (not part of include/mvk.h; tests/test_gpu_f32.py, profiles/f32_bounds.py): one pass of the fp32 screen
+// Diagnostic (include/mvk_debug.h): host calls whose fused launch gave up at its grid barrier
+extern "C" long long mvk_debug_fused_giveups(mvk_ctx* c, int reset) {
+  if (!c) return -1;
+  const long long v = c->fused_giveups;
+  if (reset) c->fused_giveups = 0;
+  return v;
+}
+
+// Diagnostic (include/mvk_debug.h; tests/test_gpu_f32.py, profiles/f32_bounds.py): one pass of the fp32 screen
 // stage over a batch that also writes, per state, what its stability classification worked with: d_lo = the
 // smallest (slack - error bound) over the tests it could bound, d_hi = the smallest (slack + error bound), d_cls =
 // 1 certainly stable / 0 certainly unstable / -1 uncertain (refined in fp64) / -2 non-finite input.
@@ -1245,7 +1259,7 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
       std::memcpy(flags, c->pin_down.p, n);
       return MVK_OK;
     }
-    // (the grid barrier gave up: never seen; the two-launch path below repeats the call)
+    // (the grid barrier gave up -- the blocks were not co-resident in time; the two-launch path below repeats the call)
   }
   // Full path on a handful of states without detail rows (mvk_is_valid, clearance queries): the kernels read the rows
   // from, and write the outputs to, pinned host memory, and the last block of distance_small_kernel raises the done

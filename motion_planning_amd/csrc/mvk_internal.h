@@ -149,6 +149,7 @@ struct EvalArgs {
   uint32_t fused_seq;      // this call's sequence number (16 bits used by first_tag)
   uint32_t* fused_bar;     // arrivals at the grid barrier
   uint32_t* fused_done;    // blocks that have finished
+  uint32_t fused_spin_limit;  // polls of the grid barrier before a block gives up (diagnostics: MVK_FUSED_SPIN_LIMIT)
   uint32_t* first_tag;     // edge mode: [n_edges] (seq << 16 | 0xFFFF - step), atomicMax: no initialisation needed
   int32_t* host_first;     // edge mode: pinned host [n_edges] first_invalid, written by the last block
   uint8_t* host_flags;     // state mode: pinned host copy of flags[n], written by the last block

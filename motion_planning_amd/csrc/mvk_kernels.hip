@@ -3259,7 +3259,6 @@ exact_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 // kernel around a grid barrier (an arrival counter in the call's counter set; the wait is bounded, a block that
 // gives up says so in the done word and the host falls back to the two launches).  Inputs are read from, verdicts
 // written to, pinned host memory directly; the last block to finish raises the done word the host polls.
-constexpr unsigned kFusedSpinLimit = 1u << 16;  // ~30 ms
 
 // the second half of a fused launch: grid barrier, exact stage, hand-over of the verdicts by the last block
 template <int ROBOT, int NL, bool EDGE>
@@ -3274,12 +3273,12 @@ DEV void fused_tail(const EvalArgs& A, const mvk_model* __restrict__ M, const De
       unsigned spins = 0, go = 1u;
       while (__hip_atomic_load(A.fused_bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
         __builtin_amdgcn_s_sleep(16);  // ~0.4 us between polls: a few hundred pollers must not crowd the arrivals out of the L2 channel
-        if (++spins > kFusedSpinLimit) { go = 0u; break; }
+        if (++spins > A.fused_spin_limit) { go = 0u; break; }
       }
       (*sm_go) = go;
     }
     __syncthreads();
-    if (!(*sm_go)) {  // (never seen; the host repeats the call with two launches)
+    if (!(*sm_go)) {  // (the host repeats the call with two launches: tests/test_gpu_fused_giveup.py forces it)
       if (threadIdx.x == 0) {
         *A.host_done = A.fused_seq | 0x80000000u;
         __threadfence_system();

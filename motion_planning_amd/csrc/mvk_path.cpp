@@ -147,7 +147,8 @@ extern "C" int mvk_cog_to_root(const mvk_model* m, const double* cog_state, doub
 //   * one filter over (root xyz, planned joints), one over the root orientation, both of factor filter_rate (0.1, :61)
 //   * both start filled with the first state (setInitValues, :76,:80)
 //   * the loop feeds the n states and then repeats the last one until index < n + 1 / filter_rate (:83-86): the
-//     output has n + floor(1 / filter_rate) states and ends ON the last state once the window holds nothing else
+//     comparison is in floating point, so the output has n + 1 / filter_rate states when that is an integer and
+//     n + ceil(1 / filter_rate) otherwise; it ends ON the last state once the window holds nothing else
 //   * [UPSTREAM-RECOLLECTION] the filter is a moving average over the last round(1 / filter_rate) inputs; the
 //     quaternion one averages the sign-aligned quaternions of the window and renormalises
 // states: row major [n][7 + J] root states (what MultilinkState holds); returns the number of states written.
@@ -156,7 +157,9 @@ extern "C" int mvk_path_smooth(const double* states, int n, int n_joint, double 
   if (!(filter_rate > 0.0 && filter_rate <= 1.0)) return fail(MVK_ERR_INVALID_ARG, "mvk_path_smooth: filter_rate must be in (0, 1]");
   const int w = 7 + n_joint;
   const int window = std::max(1, static_cast<int>(std::lround(1.0 / filter_rate)));
-  const int total = n + static_cast<int>(std::floor(1.0 / filter_rate));
+  // indices with  index < n + 1 / filter_rate  in floating point (:83): n + 1/rate states when 1/rate is an integer
+  // (the default 0.1: n + 10), n + ceil(1/rate) otherwise (0.3: n + 4)
+  const int total = static_cast<int>(std::ceil(static_cast<double>(n) + 1.0 / filter_rate - 1e-9));
   if (!out) return total;
   if (cap < total) return fail(MVK_ERR_CAPACITY, "mvk_path_smooth: output holds %d states, %d needed", cap, total);
   // ring of the last `window` inputs, all equal to the first state at the start

@@ -231,10 +231,17 @@ inline __attribute__((always_inline)) int nearest_se2_fused(const mvk_params& p,
 
 // Two passes: the compound distance of every node in fp32 (eight nodes per AVX2 operation, and fp32 square roots
 // cost a quarter of the fp64 ones -- the two per node are most of the scan), then the fp64 distance of the few nodes
-// within kNearSlack of the fp32 minimum, with the first-index rule of the one-pass scan.  Coordinates are below 10 in
-// magnitude (positions, angles), so the fp32 value is within ~5e-6 of the fp64 one: the fp64 minimum is always among
-// the candidates and the result is the one-pass scan's.
-constexpr float kNearSlack = 2e-4f;
+// within a slack of the fp32 minimum, with the first-index rule of the one-pass scan.  The slack follows from the
+// space's bounds: a coordinate of magnitude <= M rounds to fp32 within M 2^-24, a difference of two within 2 M 2^-24,
+// the planar norm within 3 M 2^-24, the sum's roundings add ~2 M 2^-24 -- about 6 (M_pos + pi + w sqrt(J) M_joint)
+// 2^-24 per node, twice that between the minimum and a candidate; 32 x is taken.  So the fp64 minimum is always among
+// the candidates and the result is the one-pass scan's, whatever the bounds (large bounds only lengthen the list).
+inline float near_slack(const mvk_params& p, int J) {
+  double mpos = 0.0, mj = 0.0;
+  for (int k = 0; k < 3; ++k) mpos = std::fmax(mpos, std::fmax(std::fabs(p.pos_low[k]), std::fabs(p.pos_high[k])));
+  for (int j = 0; j < J; ++j) mj = std::fmax(mj, std::fmax(std::fabs(p.joint_low[j]), std::fabs(p.joint_high[j])));
+  return static_cast<float>(32.0 * 5.9604645e-8 * (mpos + kPi + p.joint_subspace_weight * std::sqrt(static_cast<double>(J)) * mj));
+}
 template <int JT>
 inline __attribute__((always_inline)) int nearest_se2_two_pass(const mvk_params& p, const Tree& t, int b0, const double* s, float* __restrict__ accf) {
   const int n = t.size() - b0;
@@ -258,7 +265,7 @@ inline __attribute__((always_inline)) int nearest_se2_two_pass(const mvk_params&
   }
   float bf = INFINITY;
   for (int i = 0; i < n; ++i) bf = accf[i] < bf ? accf[i] : bf;
-  const float thr = bf + kNearSlack + 1e-5f * bf;
+  const float thr = bf + near_slack(p, JT) + 4e-7f * bf;
   // the candidates in fp64, exactly as nearest_se2_fused computes a node
   const double qx = s[0], qy = s[1], qw = s[2], w = p.joint_subspace_weight;
   double bd = INFINITY;

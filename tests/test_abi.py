@@ -12,8 +12,8 @@ from motion_planning_amd import _abi as A
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "mvk.h")).read()
+def declared_symbols(header="mvk.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mvk_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,6 +26,20 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n), f"libmvk.so does not export {n}"
         assert n in A.PROTOTYPES, f"{n} has no ctypes prototype"
     assert sorted(A.PROTOTYPES) == names
+
+
+def test_every_exported_symbol_is_declared_in_a_header():
+    """no extern "C" export of the release library outside include/ (mvk.h = the boundary,
+    mvk_debug.h = diagnostics)"""
+    import subprocess
+    lib = A.load()
+    dbg = declared_symbols("mvk_debug.h")
+    assert sorted(A.DEBUG_PROTOTYPES) == dbg
+    for n in dbg:
+        assert hasattr(lib, n), f"libmvk.so does not export {n}"
+    out = subprocess.run(["nm", "-D", "--defined-only", A.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r" T mvk_[a-z0-9_]+$", ln)})
+    assert exported == sorted(declared_symbols() + dbg), set(exported) ^ set(declared_symbols() + dbg)
 
 
 def test_struct_layouts_match():

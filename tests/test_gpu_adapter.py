@@ -22,6 +22,7 @@ def check_lib():
     vp = C.c_void_p
     lib.mvk_adapter_check_run.argtypes = [vp, C.c_int, vp, vp, C.c_int] + [vp] * 9
     lib.mvk_adapter_check_errors.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.mvk_adapter_check_clearance.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
     return lib
 
 
@@ -125,6 +126,32 @@ def test_adapter_equals_the_c_abi_and_the_oracle(case):
     assert np.array_equal(got["motions_first"][clear], first_o[clear])
     if name == "c1":
         assert got["valid_single"][0] == 1 and got["valid_single"][1] == 1 and got["motion2"][0] == 0   # through the wall
+
+
+@pytest.mark.parametrize("case", list(cases()), ids=lambda c: c[0])
+def test_adapter_clearance_is_the_signed_min_distance(case):
+    """VERDICT r2: ompl::base::StateValidityChecker::clearance / isValid(state, dist) through base-class pointers
+    (what a MaximizeClearanceValidStateSampler calls; the reference installs a valid-state-sampler allocator,
+    motion_planning.h:168-171) = mvk_result::min_dist = the oracle's signed separation."""
+    name, m, p, boxes, s1, s2 = case
+    n = len(s1)
+    eng = mp.Engine(m, boxes, p)
+    cl, d = np.zeros(n), np.zeros(n)
+    v = np.zeros(n, np.uint8)
+    err = np.zeros(1, np.uint32)
+    rc = check_lib().mvk_adapter_check_clearance(eng.ctx, m.n_joint, p_(s1), n, p_(cl), p_(v), p_(d), p_(err))
+    eng.close()
+    assert rc == 0 and err[0] == 0
+    ref = O.eval_batch(m, boxes, p, np.ascontiguousarray(s1.T), A.LAYOUT_OMPL)
+    assert np.array_equal(cl, d)                                   # one evaluation serves both virtuals
+    off_band = ~ref["band"].astype(bool)
+    assert np.array_equal(v[off_band], ref["flags"][off_band])
+    if name == "mode0":                                            # collision stage off: nothing to be clear of
+        assert np.all(np.isposinf(cl)) and np.all(np.isposinf(ref["min_dist"]))
+    else:
+        assert np.allclose(cl, ref["min_dist"], rtol=1e-5, atol=1e-12)
+        assert (cl <= 0).any() or name != "c1"
+        assert (cl > 0).any()
 
 
 def test_adapter_turns_errors_into_invalid_without_throwing():

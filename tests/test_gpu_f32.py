@@ -47,9 +47,8 @@ def debug_bounds(eng, soa, layout):
     d = torch.from_numpy(np.ascontiguousarray(soa)).cuda()
     lo, hi, cls = (torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(3))
     fl = torch.zeros(n, dtype=torch.uint8, device="cuda")
-    fn = lib.mvk_debug_f32_bounds
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int] + [C.c_void_p] * 5
-    rc = fn(eng.ctx, d.data_ptr(), n, d.stride(0), layout, fl.data_ptr(), lo.data_ptr(), hi.data_ptr(), cls.data_ptr(),
+    rc = lib.mvk_debug_f32_bounds(   # include/mvk_debug.h
+        eng.ctx, d.data_ptr(), n, d.stride(0), layout, fl.data_ptr(), lo.data_ptr(), hi.data_ptr(), cls.data_ptr(),
             torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.mvk_last_error()
     torch.cuda.synchronize()

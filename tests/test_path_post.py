@@ -186,6 +186,9 @@ def test_path_smoothing_follows_what_the_call_site_fixes():
         q = win[:, 3:7] * np.where(win[:, 3:7] @ win[-1, 3:7] < 0, -1.0, 1.0)[:, None]
         q = q.sum(0)
         assert np.allclose(got[k, 3:7], q / np.linalg.norm(q))
+    # the loop bound is compared in floating point (:83): 1 / 0.3 = 3.33 -> indices up to n + 3, n + 4 states
+    assert PP.smooth(path, 0.3).shape[0] == n + 4 and PP.smooth(path, 0.25).shape[0] == n + 4
+    assert PP.smooth(path, 0.7).shape[0] == n + 2 and PP.smooth(path, 1.0).shape[0] == n + 1
     # a constant path stays put; q and -q are the same attitude
     const = np.repeat(path[:1], 8, axis=0)
     assert np.allclose(PP.smooth(const, 0.25), np.repeat(path[:1] / np.array([1] * 3 + [np.linalg.norm(path[0, 3:7])] * 4 + [1] * J), 12, axis=0))
