@@ -308,10 +308,13 @@ int mvk_is_valid_mask_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld
  *     (two streams, two ctxs, two threads) race.  Issue them one after another in stream order.
  * Same arguments as mvk_is_valid_mask_dev and the same result bits as its fp64 path: this entry point always
  * computes in fp64, whatever mvk_set_flag_precision selected (tests/test_zz_no_alloc.py).
- * Under graph capture (`stream` is capturing): the call waits ON THE HOST for the ctx's previous call on any
- * other stream, captures a memset node and its kernels, and records nothing about itself in the ctx, so
- * launches of the graph are the caller's to keep in order with other calls on the ctx and with other users of
- * the array (tests/test_zz_no_alloc.py::test_noalloc_call_captured_into_a_graph_replays). */
+ * Under graph capture (`stream` is capturing): the call captures a memset node and its kernels and records
+ * nothing about itself in the ctx, so launches of the graph are the caller's to keep in order with other calls
+ * on the ctx and with other users of the array.  HIP refuses synchronising calls from a capturing thread, so the
+ * library cannot wait for an earlier asynchronous call itself: if the ctx's previous call went to ANOTHER stream
+ * through a *_dev entry point and nothing has waited for it since, the call is refused (MVK_ERR_INVALID_ARG,
+ * nothing captured) -- synchronise that stream, or make any blocking call on the ctx, before the capture begins
+ * (tests/test_zz_no_alloc.py::test_noalloc_call_captured_into_a_graph_replays). */
 #define MVK_NOALLOC_MAX_STATES 65536
 int mvk_is_valid_mask_noalloc_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout,
                                   uint64_t* d_mask, void* stream);
@@ -333,6 +336,38 @@ int mvk_sweep_states(const mvk_params* params, int n_joint, const double* root_p
 /* number of valid samples among the first n_bits of a packed mask, written to *d_count (device):
  * the scalar that is all-reduced across GPUs next to the mask all-gather */
 int mvk_mask_count_dev(const uint64_t* d_mask, size_t n_bits, uint64_t* d_count, void* stream);
+
+/* ---- multi-GPU exchange (BASELINE north star: "RCCL over xGMI is used only to gather valid-sample
+ * masks and reduce min-distance/margin statistics") -------------------------------------------------------------------
+ * No counterpart in the reference, which is one process (squeeze_navigation/src/planner/sampling_based_method.cpp:214-217
+ * -> MotionPlanning::plan, single-threaded ros::spin).  One process per GPU; every rank holds the whole model and scene
+ * and evaluates the index range mvk_shard_range gives it with the entry points above (no data-path collective); these
+ * calls are the only communication.  RCCL is bound at run time (librccl.so.1): MVK_ERR_NO_DEVICE when it is absent.
+ *   mvk_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by whatever
+ *                        channel the job has (file, socket, MPI, a torch.distributed store)
+ *   mvk_comm_create      ncclCommInitRank on `device`; collective: every rank of the job calls it
+ *   mvk_gather_mask_dev  ncclAllGather of the packed validity masks: every rank contributes words_per_rank words
+ *                        (its shard, zero padded), d_all receives world * words_per_rank words in rank order
+ *   mvk_allreduce_count_dev  ncclAllReduce(sum) of uint64 counters in place (e.g. mvk_mask_count_dev's output)
+ *   mvk_allreduce_stats  the mvk_stats of every rank's last batch (mvk_reduce_stats) combined: counts summed, extrema
+ *                        with their GLOBAL sample index (local index + index_offset, ties -> smallest index); one
+ *                        ncclAllGather of 104 bytes per rank + a host merge; blocks until `stream` has delivered it
+ *   mvk_merge_stats      that merge alone, on the host (records that travelled by another channel)
+ * Collectives are enqueued on `stream`; a communicator serves one stream at a time. */
+#define MVK_COMM_ID_BYTES 128
+typedef struct mvk_comm mvk_comm;
+int mvk_comm_unique_id(unsigned char* id /* [MVK_COMM_ID_BYTES] */);
+int mvk_comm_create(const unsigned char* id, int rank, int world, int device, mvk_comm** out);
+int mvk_comm_destroy(mvk_comm* comm);
+int mvk_comm_rank(const mvk_comm* comm);
+int mvk_comm_world(const mvk_comm* comm);
+/* contiguous shard [lo, hi) of n samples for `rank`, aligned to 64 so that mask words never straddle ranks;
+ * words_per_rank = the (padded) mask words every rank contributes to mvk_gather_mask_dev */
+int mvk_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi, size_t* words_per_rank);
+int mvk_gather_mask_dev(mvk_comm* comm, const uint64_t* d_shard, size_t words_per_rank, uint64_t* d_all, void* stream);
+int mvk_allreduce_count_dev(mvk_comm* comm, uint64_t* d_count, size_t n_counts, void* stream);
+int mvk_allreduce_stats(mvk_comm* comm, const mvk_stats* local, uint64_t index_offset, mvk_stats* global, void* stream);
+int mvk_merge_stats(const mvk_stats* locals, const uint64_t* offsets, int world, mvk_stats* global);
 
 /* Full evaluation with per-sample model quantities (what MultilinkState /
  * addState expose: multilink_state.cpp:98-137, motion_planning.cpp:546-642). */

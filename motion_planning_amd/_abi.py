@@ -185,6 +185,20 @@ def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmvk.so")
 
 
+PROTOTYPES.update({
+    "mvk_comm_unique_id": (ip, [vp]),
+    "mvk_comm_create": (ip, [vp, ip, ip, ip, C.POINTER(vp)]),
+    "mvk_comm_destroy": (ip, [vp]),
+    "mvk_comm_rank": (ip, [vp]),
+    "mvk_comm_world": (ip, [vp]),
+    "mvk_shard_range": (ip, [sz, ip, ip, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+    "mvk_gather_mask_dev": (ip, [vp, vp, sz, vp, vp]),
+    "mvk_allreduce_count_dev": (ip, [vp, vp, sz, vp]),
+    "mvk_allreduce_stats": (ip, [vp, C.POINTER(Stats), C.c_uint64, C.POINTER(Stats), vp]),
+    "mvk_merge_stats": (ip, [C.POINTER(Stats), C.POINTER(C.c_uint64), ip, C.POINTER(Stats)]),
+})
+COMM_ID_BYTES = 128
+
 # every symbol include/mvk_debug.h declares (diagnostics, not part of the drop-in boundary)
 DEBUG_PROTOTYPES = {
     "mvk_debug_f32_bounds": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, vp]),

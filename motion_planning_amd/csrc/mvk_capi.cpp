@@ -570,6 +570,7 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
 //   anything else (handle destroyed)  its work may still be draining: one device-wide wait, then carry on
 // and whatever happens the ctx is never left pointing at a stream it cannot use.
 bool stream_capturing(hipStream_t s) {
+  if (!s) return false;  // the legacy stream cannot be captured (and asking about it while another stream captures is itself an error)
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
   return st != hipStreamCaptureStatusNone;
@@ -594,9 +595,12 @@ int drain_order_stream(mvk_ctx* c) {
 int enter_stream(mvk_ctx* c, hipStream_t s) {
   if (!c->order_armed || s == c->order_stream) return MVK_OK;
   if (stream_capturing(s)) {
-    // the new call is being captured: a wait on an event recorded outside the capture would either fail or drop
-    // out of the graph, so the dependency on the earlier call is resolved here, on the host
-    return drain_order_stream(c);
+    // The new call is being captured: a wait on an event recorded outside the capture would either fail or drop
+    // out of the graph, and HIP refuses every synchronising call from a capturing thread (and invalidates the
+    // capture for the attempt).  So nothing of the runtime is asked here: either the ctx knows its last call has
+    // finished (every blocking entry point disarms the mark once it has waited), or the caller is told.
+    return fail(MVK_ERR_INVALID_ARG, "graph capture: the previous call on this ctx may still be running on another stream; "
+                "synchronise that stream (or call a blocking entry point) before capturing");
   }
   if (c->order_stream != c->stream) {  // a caller's stream: look before touching it
     if (stream_capturing(c->order_stream))
@@ -621,6 +625,12 @@ int leave_stream(mvk_ctx* c, hipStream_t s) {
 }
 // host wait for the last call on the ctx, whatever stream it went to
 int wait_last_call(mvk_ctx* c) { return drain_order_stream(c); }
+// a blocking entry point's wait for its own work: afterwards nothing of the ctx is in flight on `s`
+int sync_stream(mvk_ctx* c, hipStream_t s) {
+  HIP_TRY(hipStreamSynchronize(s));
+  if (c->order_armed && c->order_stream == s) c->order_armed = false;
+  return MVK_OK;
+}
 
 // ---- small host batches: one launch, no copies (fused_kernel) --------------------------------------------------
 // eligible: flag path in fp64, at most kFusedMaxBlocks blocks of lanes (all resident at once)
@@ -663,13 +673,15 @@ int fused_wait(mvk_ctx* c, uint32_t seq, hipStream_t s, int* gave_up) {
   for (unsigned spin = 0;; ++spin) {
     const uint32_t v = __atomic_load_n(const_cast<const uint32_t*>(const_cast<uint32_t*>(done)), __ATOMIC_ACQUIRE);
     if ((v & 0x7FFFFFFFu) == seq) {
-      if (v & 0x80000000u) { *gave_up = 1; ++c->fused_giveups; HIP_TRY(hipStreamSynchronize(s)); }
+      if (v & 0x80000000u) { *gave_up = 1; ++c->fused_giveups; if (int rc_ = sync_stream(c, s)) return rc_; }
+      // the done word is the last thing the launch writes: nothing of the ctx's scratch is in use any more
+      if (c->order_armed && c->order_stream == s) c->order_armed = false;
       return MVK_OK;
     }
     __builtin_ia32_pause();
     if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
   }
-  HIP_TRY(hipStreamSynchronize(s));  // a long kernel (or a busy GPU): let the runtime wait
+  if (int rc_ = sync_stream(c, s)) return rc_;  // a long kernel (or a busy GPU): let the runtime wait
   const uint32_t v = *done;
   if ((v & 0x7FFFFFFFu) != seq) return fail(MVK_ERR_HIP, "fused flag path: the kernel finished without raising its done word");
   *gave_up = (v & 0x80000000u) ? 1 : 0;
@@ -955,7 +967,7 @@ extern "C" int mvk_set_scene(mvk_ctx* c, const mvk_box* boxes, size_t n_boxes) {
   if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
   HIP_TRY(hipSetDevice(c->device));
   if (int rc = wait_last_call(c)) return rc;  // the last call may be on a caller's stream and still reading the old scene
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc_ = sync_stream(c, c->stream)) return rc_;
   return upload_scene(c, boxes, n_boxes);
 }
 
@@ -1341,7 +1353,7 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
         HIP_TRY(hipMemcpyAsync(down_d + at * dld, c->det[k].p, det_rows[k] * dld * sizeof(double), hipMemcpyDeviceToHost, s));
         at += det_rows[k];
       }
-    HIP_TRY(hipStreamSynchronize(s));
+    if (int rc_ = sync_stream(c, s)) return rc_;
     if (flags) std::memcpy(flags, down, n);
     if (band) std::memcpy(band, down + dld, n);
     if (min_dist) std::memcpy(min_dist, down_d, n * sizeof(double));
@@ -1361,7 +1373,7 @@ int eval_host(mvk_ctx* c, const double* soa, size_t n, size_t ld, int layout, ui
   for (int k = 0; k < 6; ++k)
     if (host_det[k])
       if (int rc = copy_rows(host_det[k], ld, c->det[k].p, dld, sizeof(double), n, det_rows[k], hipMemcpyDeviceToHost, s)) return rc;
-  HIP_TRY(hipStreamSynchronize(s));
+  if (int rc_ = sync_stream(c, s)) return rc_;
   return MVK_OK;
 }
 }  // namespace
@@ -1405,7 +1417,7 @@ extern "C" int mvk_reduce_stats(mvk_ctx* c, mvk_stats* out) {
   if (e != hipSuccess) return fail(MVK_ERR_HIP, "stats kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e)));
   StatsPartial h;
   HIP_TRY(hipMemcpyAsync(&h, c->stats_out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc_ = sync_stream(c, c->stream)) return rc_;
   out->n = c->last_n;
   out->valid_count = h.valid_count;
   out->band_count = h.band_count;
@@ -1558,7 +1570,7 @@ extern "C" int mvk_collision_avoidance_batch(mvk_ctx* c, const double* soa, size
     unsigned char* down = static_cast<unsigned char*>(c->pin_down.p);
     for (int k = 0; k < 7; ++k)
       if (host[k]) HIP_TRY(hipMemcpyAsync(down + off[k], dev[k], dld * nrows[k] * elem[k], hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (int rc_ = sync_stream(c, s)) return rc_;
     for (int k = 0; k < 7; ++k)
       if (host[k])
         for (size_t r = 0; r < nrows[k]; ++r)
@@ -1568,7 +1580,7 @@ extern "C" int mvk_collision_avoidance_batch(mvk_ctx* c, const double* soa, size
   for (int k = 0; k < 7; ++k)
     if (host[k])
       if (int rc = copy_rows(host[k], ld, dev[k], dld, elem[k], n, nrows[k], hipMemcpyDeviceToHost, s)) return rc;
-  HIP_TRY(hipStreamSynchronize(s));
+  if (int rc_ = sync_stream(c, s)) return rc_;
   return MVK_OK;
 }
 
@@ -1645,12 +1657,12 @@ extern "C" int mvk_check_motion_batch_dev(mvk_ctx* c, const double* d_s1, const 
     // per-edge counts: the (edge, step) -> lane map needs their prefix sums
     std::vector<int32_t> h(n_edges);
     HIP_TRY(hipMemcpyAsync(h.data(), d_nd, n_edges * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (int rc_ = sync_stream(c, s)) return rc_;
     std::vector<int64_t> off;
     prefix_counts(h.data(), n_edges, off, total);
     if (int rc = c->edge_off.reserve(n_edges * sizeof(int64_t))) return rc;
     HIP_TRY(hipMemcpyAsync(c->edge_off.p, off.data(), n_edges * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // `off` is a local
+    if (int rc_ = sync_stream(c, s)) return rc_;  // `off` is a local
     d_off = static_cast<const int64_t*>(c->edge_off.p);
   } else {
     total = static_cast<uint64_t>(n_edges) * static_cast<uint64_t>(nd_uniform < 1 ? 1 : nd_uniform);
@@ -1843,10 +1855,10 @@ extern "C" int mvk_check_motion_batch_end(mvk_ctx* c, uint8_t* ok, int32_t* firs
     if (gave_up) {  // (never seen) repeat with two launches
       if (int rc = edges_submit_two_launches(c)) return rc;
       c->edges_pending = false;
-      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (int rc_ = sync_stream(c, c->stream)) return rc_;
     }
   } else {
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc_ = sync_stream(c, c->stream)) return rc_;
   }
   if (!ok && !first_invalid) return fail(MVK_ERR_INVALID_ARG, "no output requested");
   const int32_t* down = static_cast<const int32_t*>(c->pin_down.p);

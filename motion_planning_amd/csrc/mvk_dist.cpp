@@ -1,0 +1,227 @@
+// mvk_dist.cpp -- the multi-GPU exchange of SURVEY.md 8(e) behind the C ABI: one process per GPU, index-range
+// shards, and RCCL over xGMI for the only two exchanges the path has -- the all-gather of the packed validity mask
+// and the reduction of the mvk_stats scalars.  No data-path collective exists: states and edges are independent.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1, the soname of both /opt/rocm's and PyTorch-ROCm's copy): a
+// process that already holds one -- a torch.distributed job -- shares it, a plain C++ caller gets /opt/rocm's, and
+// libmvk.so itself loads on boxes without RCCL (single-GPU users never touch this file's entry points).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "mvk_internal.h"
+
+using mvk::fail;
+
+namespace {
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+const Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.handle) break;
+    }
+    if (!r.handle) return;
+    auto sym = [&](const char* n) { return dlsym(r.handle, n); };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.GetErrorString;
+  });
+  return r;
+}
+
+int need_rccl() {
+  if (!rccl().ok) return fail(MVK_ERR_NO_DEVICE, "RCCL is not available (dlopen of librccl.so.1 failed: %s)", dlerror() ? dlerror() : "symbols missing");
+  return MVK_OK;
+}
+
+#define RCCL_TRY(expr)                                                                                   \
+  do {                                                                                                   \
+    const ncclResult_t r_ = (expr);                                                                      \
+    if (r_ != ncclSuccess) return fail(MVK_ERR_HIP, "%s failed: %s", #expr, rccl().GetErrorString(r_)); \
+  } while (0)
+#define HIPD_TRY(expr)                                                                              \
+  do {                                                                                              \
+    const hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(MVK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// what a rank contributes to the statistics exchange: three counts, five extrema with their GLOBAL sample index
+struct StatsRec {
+  uint64_t count[3];
+  double value[5];
+  int64_t index[5];
+};
+static_assert(sizeof(StatsRec) == 13 * 8, "StatsRec is exchanged as 13 64-bit words");
+
+}  // namespace
+
+struct mvk_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  // staging of the statistics exchange: world records on the device, pinned on the host (made once, here)
+  StatsRec* d_rec = nullptr;
+  StatsRec* h_rec = nullptr;
+};
+
+extern "C" int mvk_comm_unique_id(unsigned char* id) {
+  if (!id) return fail(MVK_ERR_INVALID_ARG, "mvk_comm_unique_id: null id");
+  if (int rc = need_rccl()) return rc;
+  static_assert(MVK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "mvk.h and rccl.h disagree on the id size");
+  ncclUniqueId u;
+  RCCL_TRY(rccl().GetUniqueId(&u));
+  std::memcpy(id, u.internal, MVK_COMM_ID_BYTES);
+  return MVK_OK;
+}
+
+extern "C" int mvk_comm_create(const unsigned char* id, int rank, int world, int device, mvk_comm** out) {
+  if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(MVK_ERR_INVALID_ARG, "mvk_comm_create: bad argument (rank %d of %d)", rank, world);
+  *out = nullptr;
+  if (int rc = need_rccl()) return rc;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) {
+    (void)hipGetLastError();
+    return fail(MVK_ERR_NO_DEVICE, "mvk_comm_create: device %d not present (%d visible)", device, n_dev);
+  }
+  HIPD_TRY(hipSetDevice(device));
+  mvk_comm* c = new (std::nothrow) mvk_comm;
+  if (!c) return fail(MVK_ERR_HIP, "mvk_comm_create: out of host memory");
+  c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, MVK_COMM_ID_BYTES);
+  const ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return fail(MVK_ERR_HIP, "ncclCommInitRank (rank %d of %d, device %d) failed: %s", rank, world, device, rccl().GetErrorString(r));
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&c->d_rec), sizeof(StatsRec) * (static_cast<size_t>(world) + 1)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&c->h_rec), sizeof(StatsRec) * (static_cast<size_t>(world) + 1), hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)mvk_comm_destroy(c);
+    return fail(MVK_ERR_HIP, "mvk_comm_create: staging buffers");
+  }
+  *out = c;
+  return MVK_OK;
+}
+
+extern "C" int mvk_comm_destroy(mvk_comm* c) {
+  if (!c) return MVK_OK;
+  (void)hipSetDevice(c->device);
+  if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+  if (c->d_rec) (void)hipFree(c->d_rec);
+  if (c->h_rec) (void)hipHostFree(c->h_rec);
+  delete c;
+  return MVK_OK;
+}
+
+extern "C" int mvk_comm_rank(const mvk_comm* c) { return c ? c->rank : -1; }
+extern "C" int mvk_comm_world(const mvk_comm* c) { return c ? c->world : -1; }
+
+// rank r owns samples [r * per * 64, ...): the same rule as the Python layer (motion_planning_amd/dist.py)
+extern "C" int mvk_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi, size_t* words_per_rank) {
+  if (world < 1 || rank < 0 || rank >= world) return fail(MVK_ERR_INVALID_ARG, "mvk_shard_range: rank %d of %d", rank, world);
+  const size_t words = (n + 63) / 64, per = (words + static_cast<size_t>(world) - 1) / static_cast<size_t>(world);
+  if (lo) *lo = std::min(n, static_cast<size_t>(rank) * per * 64);
+  if (hi) *hi = std::min(n, (static_cast<size_t>(rank) + 1) * per * 64);
+  if (words_per_rank) *words_per_rank = per;
+  return MVK_OK;
+}
+
+extern "C" int mvk_gather_mask_dev(mvk_comm* c, const uint64_t* d_shard, size_t words_per_rank, uint64_t* d_all, void* stream) {
+  if (!c || !d_shard || !d_all) return fail(MVK_ERR_INVALID_ARG, "mvk_gather_mask_dev: null argument");
+  if (words_per_rank == 0) return MVK_OK;
+  HIPD_TRY(hipSetDevice(c->device));
+  RCCL_TRY(rccl().AllGather(d_shard, d_all, words_per_rank, ncclUint64, c->comm, static_cast<hipStream_t>(stream)));
+  return MVK_OK;
+}
+
+extern "C" int mvk_allreduce_count_dev(mvk_comm* c, uint64_t* d_count, size_t n_counts, void* stream) {
+  if (!c || !d_count) return fail(MVK_ERR_INVALID_ARG, "mvk_allreduce_count_dev: null argument");
+  if (n_counts == 0) return MVK_OK;
+  HIPD_TRY(hipSetDevice(c->device));
+  RCCL_TRY(rccl().AllReduce(d_count, d_count, n_counts, ncclUint64, ncclSum, c->comm, static_cast<hipStream_t>(stream)));
+  return MVK_OK;
+}
+
+// the merge of per-rank records, also used without a communicator (tests, world == 1)
+static void merge_stats(const StatsRec* recs, int world, mvk_stats* g) {
+  std::memset(g, 0, sizeof(*g));
+  double best[5] = {INFINITY, INFINITY, -INFINITY, INFINITY, INFINITY};  // min_dist, min_margin, max_thrust, min_thrust, min_rp
+  int64_t at[5] = {-1, -1, -1, -1, -1};
+  for (int r = 0; r < world; ++r) {
+    g->n += recs[r].count[0]; g->valid_count += recs[r].count[1]; g->band_count += recs[r].count[2];
+    for (int k = 0; k < 5; ++k) {
+      if (recs[r].index[k] < 0) continue;  // that rank saw no sample for this statistic
+      const double v = recs[r].value[k];
+      const bool better = k == 2 ? v > best[k] : v < best[k];
+      // ties keep the smallest global index, as one device reduction over the whole batch would
+      if (at[k] < 0 || better || (v == best[k] && recs[r].index[k] < at[k])) { best[k] = v; at[k] = recs[r].index[k]; }
+    }
+  }
+  g->min_dist = best[0]; g->min_dist_index = at[0];
+  g->min_margin = best[1]; g->min_margin_index = at[1];
+  g->max_thrust = best[2]; g->max_thrust_index = at[2];
+  g->min_thrust = best[3]; g->min_thrust_index = at[3];
+  g->min_rp_position_margin = best[4]; g->min_rp_position_margin_index = at[4];
+}
+
+extern "C" int mvk_allreduce_stats(mvk_comm* c, const mvk_stats* local, uint64_t index_offset, mvk_stats* global, void* stream) {
+  if (!c || !local || !global) return fail(MVK_ERR_INVALID_ARG, "mvk_allreduce_stats: null argument");
+  HIPD_TRY(hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  StatsRec& mine = c->h_rec[c->world];  // slot behind the gathered table
+  mine.count[0] = local->n; mine.count[1] = local->valid_count; mine.count[2] = local->band_count;
+  const double v[5] = {local->min_dist, local->min_margin, local->max_thrust, local->min_thrust, local->min_rp_position_margin};
+  const int64_t ix[5] = {local->min_dist_index, local->min_margin_index, local->max_thrust_index, local->min_thrust_index,
+                         local->min_rp_position_margin_index};
+  for (int k = 0; k < 5; ++k) {
+    mine.value[k] = v[k];
+    mine.index[k] = ix[k] < 0 ? -1 : ix[k] + static_cast<int64_t>(index_offset);
+  }
+  HIPD_TRY(hipMemcpyAsync(c->d_rec + c->world, &mine, sizeof(StatsRec), hipMemcpyHostToDevice, s));
+  RCCL_TRY(rccl().AllGather(c->d_rec + c->world, c->d_rec, sizeof(StatsRec) / 8, ncclUint64, c->comm, s));
+  HIPD_TRY(hipMemcpyAsync(c->h_rec, c->d_rec, sizeof(StatsRec) * static_cast<size_t>(c->world), hipMemcpyDeviceToHost, s));
+  HIPD_TRY(hipStreamSynchronize(s));
+  merge_stats(c->h_rec, c->world, global);
+  return MVK_OK;
+}
+
+// host-only form of the merge: `locals[r]` with its shard's first global index `offsets[r]` (what rank 0 would do
+// with records that reached it by any other channel; the gloo tests pin the rule against the Python layer)
+extern "C" int mvk_merge_stats(const mvk_stats* locals, const uint64_t* offsets, int world, mvk_stats* global) {
+  if (!locals || !offsets || !global || world < 1) return fail(MVK_ERR_INVALID_ARG, "mvk_merge_stats: bad argument");
+  std::vector<StatsRec> recs(static_cast<size_t>(world));
+  for (int r = 0; r < world; ++r) {
+    const mvk_stats& l = locals[r];
+    recs[r].count[0] = l.n; recs[r].count[1] = l.valid_count; recs[r].count[2] = l.band_count;
+    const double v[5] = {l.min_dist, l.min_margin, l.max_thrust, l.min_thrust, l.min_rp_position_margin};
+    const int64_t ix[5] = {l.min_dist_index, l.min_margin_index, l.max_thrust_index, l.min_thrust_index, l.min_rp_position_margin_index};
+    for (int k = 0; k < 5; ++k) { recs[r].value[k] = v[k]; recs[r].index[k] = ix[k] < 0 ? -1 : ix[k] + static_cast<int64_t>(offsets[r]); }
+  }
+  merge_stats(recs.data(), world, global);
+  return MVK_OK;
+}

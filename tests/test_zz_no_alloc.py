@@ -78,10 +78,23 @@ def test_noalloc_call_captured_into_a_graph_replays():
     ref = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(2)]
     for k in range(2):
         eng.is_valid_mask_dev(torch.from_numpy(np.ascontiguousarray(w.soa[:, k * n:(k + 1) * n])).to(dev), w.layout, ref[k])
-    host_flags = eng.is_valid_batch(w.soa[:, :512], w.layout)["flags"]      # a host call: the ctx's own stream
+    side = torch.cuda.Stream(device=dev)
+    # an asynchronous call still "in flight" for all the ctx knows (another stream, nobody waited): the capture of the
+    # next call must be refused cleanly -- before the capture begins here, so the refusal costs no capture
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        g0 = torch.cuda.CUDAGraph()
+        g0.capture_begin(capture_error_mode="thread_local")
+        try:
+            with pytest.raises(mp.MvkError) as e:
+                eng.is_valid_mask_noalloc_dev(d_in, w.layout, d_mask, stream=side)
+            assert "graph capture" in str(e.value)
+        finally:
+            g0.capture_end()
+    del g0
+    host_flags = eng.is_valid_batch(w.soa[:, :512], w.layout)["flags"]      # a blocking host call: the ctx's own stream
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(side):
         g.capture_begin(capture_error_mode="thread_local")
         eng.is_valid_mask_noalloc_dev(d_in, w.layout, d_mask, stream=side)
