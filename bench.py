@@ -148,10 +148,12 @@ def distance_roofline(workload, kernel, n, ms):
     """VALU-issue roofline of a distance kernel, as roofline_of: executed wave instructions per launch (committed PMC
     pass, scaled to n states) / the time measured here / 6.144e11 per s.  None when no PMC pass is committed."""
     ent = pmc_traffic(workload + ".distance") or {}
+    if ent.get("stale"):
+        return {"bound": "valu_fp64", "kernel": kernel, "frac": None, "stale_pmc": ent["stale"]}
     k = ent.get(kernel)
     if not k:
         return None
-    insts = k["valu_insts_per_launch"] * n / k.get("states_per_launch", ent["states_per_launch"])
+    insts = k["valu_insts_per_launch"] * n / (k.get("states_per_launch") or ent["states_per_launch"])
     return {"bound": "valu_fp64", "kernel": kernel, "frac": insts / (ms * 1e-3) / 6.144e11,
             "frac_definition": "executed VALU wave instructions per launch (PMC SQ_INSTS_VALU) / ms / 6.144e11 per s; ms here includes "
                                "model_kernel (3-5 % of the call)" if kernel == "distance_kernel" else
@@ -263,6 +265,9 @@ def roofline_of(workload, w, n, screen_ms, exact_ms, call_ms, sweep):
     b_alg = (0 if sweep else 8 * (7 + J)) + 1.0 / 8.0
     t = screen_ms * 1e-3
     pmc = pmc_traffic(workload) or {}
+    stale = pmc.get("stale")
+    if stale:
+        pmc = {"source": pmc.get("source")}
     insts = pmc.get("valu_insts_per_launch")
     scale = n / pmc["states_per_launch"] if insts and pmc.get("states_per_launch") else 1.0
     rate = insts * scale / t if insts else None
@@ -273,7 +278,11 @@ def roofline_of(workload, w, n, screen_ms, exact_ms, call_ms, sweep):
             "valu_wave_insts_per_launch": insts * scale if insts else None,
             "valu_busy_pmc": pmc.get("valu_busy"),
             "traffic": pmc.get("hbm_bytes_per_launch"),
+            "stale_pmc": stale,
             "kernel_ms": screen_ms, "second_kernel": "exact_kernel", "second_kernel_ms": exact_ms, "call_ms": call_ms,
+            "kernel_ms_note": "kernel_ms / second_kernel_ms come from a separate pass with HIP event markers between the launches "
+                              "(mvk_set_profiling), call_ms from events around whole calls; the timed region carries neither, so "
+                              "their sum can exceed ms_per_step by a few per cent",
             "bytes_per_check": b_alg, "flop_per_check_uncullable": f_model, "flop_per_check_allpairs": f_alg,
             "achieved_uncullable_tflops": n * f_model / t / 1e12,
             "cull_gain_vs_allpairs": n * f_alg / t / 1e12 / PEAK_FP64_VALU_TFLOPS,
@@ -289,8 +298,10 @@ def workload_leg(name, n, dev, steps=10, warmup=2):
     import common
     import motion_planning_amd as mp
     statics_only = name == "c5_statics"   # the mode-0 sweep of scripts/state_validation_l4.py:46-68 (joints only, no collision)
-    w = make_workload("c5" if statics_only else name, n)
-    sweep = name in ("c5", "c5_statics")
+    if name == "c5_8m":   # BASELINE config 5 at its per-GPU size: 64 M samples over 8 GPUs = 8 M per launch
+        n = 1 << 23
+    w = make_workload("c5" if name.startswith("c5") else name, n)
+    sweep = name.startswith("c5")
     if statics_only:
         from motion_planning_amd import _abi as A
         w.params = mp.default_params(w.model, A.MODE_ONLY_JOINTS, A.SE2)
@@ -327,7 +338,7 @@ def workload_leg(name, n, dev, steps=10, warmup=2):
                         + (", states generated in-kernel (C-space sweep)" if sweep else "")
                         + (", planning mode 0: joints only, stability verdict alone" if statics_only else ""),
             "ms_per_step": ms, "checks_per_s": n / ms * 1e3, "steps": steps, "valid_fraction": float(bits.mean()),
-            "roofline": None if statics_only else roofline_of(name, w, n, screen_ms, exact_ms, ms, sweep),
+            "roofline": None if statics_only else roofline_of("c5" if name == "c5_8m" else name, w, n, screen_ms, exact_ms, ms, sweep),
             "kernel_ms": [screen_ms, exact_ms]}
 
 
@@ -369,16 +380,36 @@ def fp32_variant(eng, w, d_soa, n, dev, steps=10):
             "mismatches_vs_f64_flag_path": int(diff.sum()), "mismatches_outside_band": int((diff & ~inb).sum())}
 
 
+_FINGERPRINT = None
+
+
+def kernel_fingerprint():
+    global _FINGERPRINT
+    if _FINGERPRINT is None:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from fingerprint import kernel_fingerprint as fp
+        _FINGERPRINT = fp(ROOT)
+    return _FINGERPRINT
+
+
 def pmc_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/latest_pmc.json, written by profiles/summarize.py; FETCH_SIZE already doubled per the
-    gfx950 correction of MI355X_MICROARCH.md).  None when no profile of this workload is committed."""
+    """Counters of the dominant kernel from the committed rocprofv3 PMC passes (profiles/latest_pmc.json, written by
+    profiles/summarize.py; FETCH_SIZE already doubled per the gfx950 correction of MI355X_MICROARCH.md).  An entry is
+    used only when it was collected from the kernel sources this run is built from (profiles/fingerprint.py: sha256
+    over mvk_kernels.hip, mvk_internal.h, mvk.h, stored at collection time): counters of another kernel version would
+    make roofline.frac silently stale.  Returns None (no entry) or {"stale": reason} instead."""
     path = os.path.join(ROOT, "profiles", "latest_pmc.json")
     try:
         d = json.load(open(path)).get(workload)
-        return d
     except (OSError, ValueError):
         return None
+    if d is None:
+        return None
+    have, want = d.get("kernel_fingerprint"), kernel_fingerprint()
+    if have != want:
+        return {"stale": f"PMC pass {d.get('source')} was collected from kernel sources {have}, this run is built from {want}: "
+                         "re-run profiles/run_profile.sh", "source": d.get("source")}
+    return d
 
 
 def bench_edges(args, world, rank, local_rank, dev):
@@ -475,6 +506,10 @@ def main():
     ap.add_argument("--no-planner", action="store_true")
     ap.add_argument("--no-edges", action="store_true")
     ap.add_argument("--no-distance", action="store_true", help="skip the distance-kernel leg (full path, avoidance rows)")
+    ap.add_argument("--exchange", default="mvk", choices=["mvk", "torch"],
+                    help="who issues the per-step mask all-gather: the library's C ABI (mvk_gather_mask_dev, RCCL called from "
+                         "libmvk.so; default) or torch.distributed (diagnostics)")
+    ap.add_argument("--cold-steps", type=int, default=20, help="N = 1: timed steps of the from-cold pass before the pre-warm (0: skip)")
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="one rank: run the step's RCCL exchange (a group of one) exactly as the N > 1 path issues it")
     args = ap.parse_args()
@@ -499,6 +534,25 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    comm = None
+    if exchange and args.exchange == "mvk":
+        # the library's own communicator (csrc/mvk_dist.cpp: ncclCommInitRank from libmvk.so); the 128-byte id travels
+        # over the process group the launcher set up, which also serves the barrier and the max-over-ranks below
+        import ctypes as C
+        from motion_planning_amd import _abi as A
+        lib = A.load()
+        ident = torch.zeros(A.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            buf = (C.c_ubyte * A.COMM_ID_BYTES)()
+            if lib.mvk_comm_unique_id(buf) != 0:
+                raise SystemExit("mvk_comm_unique_id: " + lib.mvk_last_error().decode())
+            ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        dist.broadcast(ident, 0)
+        buf = (C.c_ubyte * A.COMM_ID_BYTES)(*ident.cpu().tolist())
+        comm = C.c_void_p()
+        if lib.mvk_comm_create(buf, rank, world, local_rank, C.byref(comm)) != 0:
+            raise SystemExit(f"rank {rank}: mvk_comm_create: " + lib.mvk_last_error().decode())
 
     if args.workload == "c4":
         return bench_edges(args, world, rank, local_rank, dev)
@@ -544,6 +598,18 @@ def main():
     ready = [torch.cuda.Event() for _ in range(n_slot)] if exchange else []
     used = [False] * n_slot
 
+    if comm is not None:
+        side_handle = C.c_void_p(side.cuda_stream)
+        mask_ptrs = [C.c_void_p(t.data_ptr()) for t in d_masks]
+        all_ptrs = [C.c_void_p(t.data_ptr()) for t in d_alls]
+
+        def gather(slot):
+            if lib.mvk_gather_mask_dev(comm, mask_ptrs[slot], words, all_ptrs[slot], side_handle) != 0:
+                raise SystemExit("mvk_gather_mask_dev: " + lib.mvk_last_error().decode())
+    else:
+        def gather(slot):
+            dist.all_gather_into_tensor(d_alls[slot], d_masks[slot])   # (current stream = side; the host does not block)
+
     def step(k, ev=None):
         slot = k % n_slot
         if exchange and used[slot]:   # this set's last exchange (step k-2) must be through before it is refilled
@@ -558,7 +624,7 @@ def main():
         if exchange:
             ready[slot].record(main_stream)
             side.wait_event(ready[slot])
-            dist.all_gather_into_tensor(d_alls[slot], d_masks[slot])   # (current stream = side; the host does not block)
+            gather(slot)   # RCCL all-gather on the side stream; the host does not block
             eng.mask_count_dev(d_alls[slot], world * words * 64, d_cnts[slot], stream=side)
             done[slot].record(side)
             used[slot] = True
@@ -569,6 +635,20 @@ def main():
                 main_stream.wait_event(done[slot])
 
     eng.set_profiling(False)   # the library's event records are markers in the queue: not inside the timed region
+    cold = None
+    if world == 1 and not exchange and args.cold_steps > 0 and args.prewarm > 0:
+        # from cold: the driver's W warm-up steps and then `cold_steps` timed ones straight out of the idle spell that
+        # building the workload left (clocks still ramping up) -- what a single batch after a pause sees; the headline
+        # below is the steady state of a caller that checks batch after batch (print both)
+        torch.cuda.synchronize()
+        for k in range(args.warmup):
+            step(k)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for k in range(args.cold_steps):
+            step(k)
+        torch.cuda.synchronize()
+        cold = (time.perf_counter() - tc) / args.cold_steps
     # (--prewarm untimed steps first: the GPU's clocks are up before the W warm-up steps and the K timed ones, see prewarm())
     if exchange:
         torch.cuda.set_stream(side)
@@ -615,7 +695,7 @@ def main():
         dist.barrier()
         e0.record(side)
         for _ in range(10):
-            dist.all_gather_into_tensor(d_alls[0], d_masks[0])
+            gather(0)
             eng.mask_count_dev(d_alls[0], world * words * 64, d_cnts[0], stream=side)
         e1.record(side)
         torch.cuda.synchronize()
@@ -637,6 +717,10 @@ def main():
             "warmup": args.warmup,
             "prewarm_steps": args.prewarm,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "value_cold": n / cold if cold else None,
+            "ms_per_step_cold": cold * 1e3 if cold else None,
+            "cold_note": f"{args.cold_steps} steps timed right after {args.warmup} warm-up steps, before the {args.prewarm} pre-warm steps: GPU clocks "
+                         "still ramping up out of the idle spell of set-up; `value` is the steady state after the pre-warm" if cold else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -646,12 +730,13 @@ def main():
                                    f"{P} robot primitives, flags as packed mask" + (", states generated in-kernel (C-space sweep)" if sweep else ""),
                        "samples_per_gpu": n, "obstacles": M, "links": NL, "parallelism": f"shard{world}"},
             "roofline": roofline_of(args.workload, w, n, screen_ms, exact_ms, call_ms, sweep),
-            "rccl_ranks": dist.get_world_size() if exchange else 1,
+            "rccl_ranks": (lib.mvk_comm_world(comm) if comm is not None else dist.get_world_size()) if exchange else 1,
             "valid_in_first_4096_words": valid,
         }
         if exchange:
             last = (args.steps - 1) % n_slot
             out["valid_total_last_step"] = int(d_cnts[last].item())   # all-reduced over ranks (mvk_mask_count_dev + RCCL sum)
+            out["exchange_by"] = "libmvk.so (mvk_gather_mask_dev -> ncclAllGather, csrc/mvk_dist.cpp)" if comm is not None else "torch.distributed"
             out["exchange"] = "per step: all-gather of the packed masks, valid count of the whole job from the gathered words on every rank; overlapped with the next step's kernels"
             out["exchange_ms"] = exchange_ms   # one exchange alone (max over ranks): what the overlap hides
             out["host_issue_ms_per_step"] = t_issued / args.steps * 1e3   # rank 0's host loop: launches + exchange calls
@@ -662,7 +747,7 @@ def main():
         if not args.no_edges and world == 1:
             out["edge_checks"] = edge_checks(dev)
         if not args.no_legs and world == 1:
-            out["workloads"] = {k: workload_leg(k, n, dev) for k in ("c2", "c3", "c5", "c5_statics") if k != args.workload}
+            out["workloads"] = {k: workload_leg(k, n, dev) for k in ("c2", "c3", "c5", "c5_8m", "c5_statics") if k != args.workload}
         if not args.no_distance and world == 1 and not sweep:
             out["distance_path"] = distance_path(eng, w, d_soa, dev, args.workload)
         if not args.no_distance and world == 1 and not sweep:
@@ -673,6 +758,8 @@ def main():
             out["fp32_variant"] = fp32_variant(eng, w, d_soa, n, dev)
         emit_line(out)
     eng.close()
+    if comm is not None:
+        lib.mvk_comm_destroy(comm)
     if exchange:
         dist.destroy_process_group()
 

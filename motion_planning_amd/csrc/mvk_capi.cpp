@@ -160,6 +160,7 @@ struct mvk_ctx {
   hipEvent_t order_ev = nullptr;
   hipStream_t order_stream = nullptr;
   bool order_armed = false;
+  bool order_recorded = false;  // order_ev already sits behind the last call's work (caller-created streams: eagerly)
   // staging for the host-pointer entry points
   Buf in_a, in_b, flags, band, mind, margin, det[6], nd, ok, first, edge_off, av[7];
   // host edge checks (the planner's inner loop): one pinned upload blob, one pinned download
@@ -561,35 +562,31 @@ void base_args(const mvk_ctx* c, EvalArgs& a) {
 // the last one's first makes its stream wait for the last call's work; every call leaves its own mark behind.
 //
 // The last call's stream may be the CALLER's (every _dev entry point takes one), and by the time the next call
-// arrives it may be idle, destroyed, or under graph capture.  Nothing is recorded on it without looking first:
-//   hipStreamQuery == hipSuccess      nothing of ours is left on it: no dependency to add
-//   hipStreamQuery == hipErrorNotReady  alive and busy: record the mark there, make the new stream wait (the lazy
-//                                     form: calls that stay on one stream never pay for an event between launches)
-//   capturing                         an event cannot be recorded outside the capture: the call is refused with a
-//                                     message, the ctx's state is untouched (it works again once the capture ended)
-//   anything else (handle destroyed)  its work may still be draining: one device-wide wait, then carry on
-// and whatever happens the ctx is never left pointing at a stream it cannot use.
+// arrives it may have been destroyed -- and HIP does not survive being asked about a destroyed stream (a query, a
+// record, even hipStreamIsCapturing on the stale handle is a use after free).  So a caller-created stream is only
+// ever touched while the call that was handed it is still running:
+//   * a call on a caller-created stream records the mark (order_ev) behind its work EAGERLY, before it returns;
+//   * a call on the ctx's own stream or on the null stream (neither can be destroyed) records nothing: the mark is
+//     recorded lazily, when a call on another stream needs it -- calls that stay on one of these streams, the usual
+//     case and bench.py's, never pay for an event between their launches;
+//   * later calls use the EVENT only (hipStreamWaitEvent / hipEventSynchronize), never the old stream handle.
+// A call that is being captured into a graph ran nothing and leaves no mark; a call captured while the ctx's last
+// call may still be running elsewhere is refused (HIP forbids the waits that would be needed, see below).
 bool stream_capturing(hipStream_t s) {
   if (!s) return false;  // the legacy stream cannot be captured (and asking about it while another stream captures is itself an error)
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
   return st != hipStreamCaptureStatusNone;
 }
-// host wait for whatever the ctx last enqueued on `order_stream`, without trusting the handle
+// host wait for whatever the ctx last enqueued, without using a caller's stream handle
 int drain_order_stream(mvk_ctx* c) {
   if (!c->order_armed) return MVK_OK;
-  if (c->order_stream != c->stream && stream_capturing(c->order_stream))
-    return fail(MVK_ERR_INVALID_ARG, "the stream of the previous call on this ctx is under graph capture: end the capture first");
-  const hipError_t q = c->order_stream == c->stream ? hipErrorNotReady : hipStreamQuery(c->order_stream);
-  if (q == hipErrorNotReady) {
-    if (hipStreamSynchronize(c->order_stream) == hipSuccess) { c->order_armed = false; return MVK_OK; }
-  } else if (q == hipSuccess) {
-    c->order_armed = false;
-    return MVK_OK;
-  }
-  (void)hipGetLastError();  // stale handle: the stream's work may still be running
+  const hipError_t e = c->order_recorded ? hipEventSynchronize(c->order_ev) : hipStreamSynchronize(c->order_stream);
   c->order_armed = false;
-  HIP_TRY(hipDeviceSynchronize());
+  if (e != hipSuccess) {  // (e.g. the event's stream died with work pending): one device-wide wait instead
+    (void)hipGetLastError();
+    HIP_TRY(hipDeviceSynchronize());
+  }
   return MVK_OK;
 }
 int enter_stream(mvk_ctx* c, hipStream_t s) {
@@ -602,25 +599,34 @@ int enter_stream(mvk_ctx* c, hipStream_t s) {
     return fail(MVK_ERR_INVALID_ARG, "graph capture: the previous call on this ctx may still be running on another stream; "
                 "synchronise that stream (or call a blocking entry point) before capturing");
   }
-  if (c->order_stream != c->stream) {  // a caller's stream: look before touching it
-    if (stream_capturing(c->order_stream))
-      return fail(MVK_ERR_INVALID_ARG, "the stream of the previous call on this ctx is under graph capture: end the capture first");
-    const hipError_t q = hipStreamQuery(c->order_stream);
-    if (q == hipSuccess) { c->order_armed = false; return MVK_OK; }
-    if (q != hipErrorNotReady) { (void)hipGetLastError(); return drain_order_stream(c); }
+  hipError_t e = hipSuccess;
+  if (!c->order_recorded) {  // the lazy mark: order_stream is the ctx's own or the null stream here, alive by construction
+    e = hipEventRecord(c->order_ev, c->order_stream);
+    c->order_recorded = e == hipSuccess;
   }
-  if (hipEventRecord(c->order_ev, c->order_stream) != hipSuccess || hipStreamWaitEvent(s, c->order_ev, 0) != hipSuccess) {
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, c->order_ev, 0);
+  if (e != hipSuccess) {
     (void)hipGetLastError();
     return drain_order_stream(c);
   }
   return MVK_OK;
 }
 int leave_stream(mvk_ctx* c, hipStream_t s) {
+  const bool callers = s != c->stream && s != nullptr;
   // a call captured into a graph ran nothing: there is no work of it to order later calls behind (the graph's
   // launches are the caller's to order against other users of the ctx, mvk.h)
-  if (s != c->stream && stream_capturing(s)) return MVK_OK;
+  if (callers && stream_capturing(s)) return MVK_OK;
   c->order_stream = s;
   c->order_armed = true;
+  c->order_recorded = false;
+  if (callers) {  // while the stream is certainly alive
+    if (hipEventRecord(c->order_ev, s) == hipSuccess) c->order_recorded = true;
+    else {        // cannot mark it: wait for it here, once, rather than trust the handle later
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(s);
+      c->order_armed = false;
+    }
+  }
   return MVK_OK;
 }
 // host wait for the last call on the ctx, whatever stream it went to

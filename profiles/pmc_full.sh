@@ -5,6 +5,7 @@ TAG=$1; W=$2
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmcfull_${TAG}_$W
 mkdir -p $OUT
+python3 $ROOT/profiles/fingerprint.py $ROOT > $OUT/kernel_fingerprint.txt
 cd /tmp && export TMPDIR=/tmp
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM" "FETCH_SIZE" "GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)

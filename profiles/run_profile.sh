@@ -6,6 +6,7 @@ TAG=${1:-r01}; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+python3 $ROOT/profiles/fingerprint.py $ROOT > $OUT/kernel_fingerprint.txt
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-planner --no-edges --no-legs --no-distance --no-fp32 $@"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }

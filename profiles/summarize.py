@@ -26,6 +26,9 @@ def main():
     out = sys.argv[1]
     args = sys.argv[2:]
     opt = {args[i][2:]: args[i + 1] for i in range(0, len(args) - 1, 2) if args[i].startswith("--")}
+    fp_file = os.path.join(out, "kernel_fingerprint.txt")
+    fingerprint = open(fp_file).read().strip() if os.path.exists(fp_file) else None
+    print(f"== kernel source fingerprint at collection time: {fingerprint} (profiles/fingerprint.py) ==")
     print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
@@ -47,6 +50,21 @@ def main():
             wait = mean.get((kx, "SQ_WAIT_ANY"), float("nan")) / mean[(kx, "SQ_WAVE_CYCLES")] if (kx, "SQ_WAVE_CYCLES") in mean else float("nan")
             print(f"== {kx}: valu_busy {busy:.3f}, wait_any/wave_cycles {wait:.3f}, valu_insts_per_wave {mean[(kx, 'SQ_INSTS_VALU')] / mean[(kx, 'SQ_WAVES')]:.0f}, "
                   f"vmem_insts_per_wave {mean.get((kx, 'SQ_INSTS_VMEM'), float('nan')) / mean[(kx, 'SQ_WAVES')]:.0f}, waves {mean[(kx, 'SQ_WAVES')]:.0f}")
+    if "merge" in opt and opt.get("kind") == "distance":
+        # pmc_full.sh passes over the distance kernels: one entry "<workload>.distance" with a record per kernel
+        try:
+            d = json.load(open(opt["merge"]))
+        except (OSError, ValueError):
+            d = {}
+        ent = {"source": opt.get("source", os.path.basename(out.rstrip("/"))), "kernel_fingerprint": fingerprint}
+        for kx in KERNELS:
+            if (kx, "SQ_INSTS_VALU") in mean and (kx, "GRBM_GUI_ACTIVE") in mean and kx not in ("screen_kernel", "exact_kernel", "screen32_kernel", "fused_kernel"):
+                ent[kx] = {"valu_insts_per_launch": mean[(kx, "SQ_INSTS_VALU")], "states_per_launch": float(opt.get("states_" + kx, opt.get("states", 0)) or 0) or None,
+                           "valu_busy": 4.0 * mean[(kx, "SQ_ACTIVE_INST_VALU")] / (mean[(kx, "GRBM_GUI_ACTIVE")] / 8.0 * 1024.0),
+                           "wait_any_frac": mean.get((kx, "SQ_WAIT_ANY"), 0.0) / mean[(kx, "SQ_WAVE_CYCLES")] if (kx, "SQ_WAVE_CYCLES") in mean else None}
+        d[opt.get("workload", "c2k") + ".distance"] = ent
+        json.dump(d, open(opt["merge"], "w"), indent=1, sort_keys=True)
+        return
     kn = "screen_kernel"
     if (kn, "FETCH_SIZE") in mean and (kn, "GRBM_GUI_ACTIVE") in mean:
         hbm = (2.0 * mean[(kn, "FETCH_SIZE")] + mean.get((kn, "WRITE_SIZE"), 0.0)) * 1024.0
@@ -62,6 +80,7 @@ def main():
                                            "valu_insts_per_launch": mean[(kn, "SQ_INSTS_VALU")],
                                            "states_per_launch": mean[(kn, "SQ_WAVES")] * 64.0,
                                            "wait_any_frac": mean.get((kn, "SQ_WAIT_ANY"), 0.0) / mean[(kn, "SQ_WAVE_CYCLES")] if (kn, "SQ_WAVE_CYCLES") in mean else None,
+                                           "kernel_fingerprint": fingerprint,
                                            "source": opt.get("source", os.path.basename(out.rstrip("/")))}
             json.dump(d, open(opt["merge"], "w"), indent=1, sort_keys=True)
 
