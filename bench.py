@@ -599,9 +599,10 @@ def main():
     used = [False] * n_slot
 
     if comm is not None:
-        side_handle = C.c_void_p(side.cuda_stream)
+        side_handle, main_handle = C.c_void_p(side.cuda_stream), C.c_void_p(main_stream.cuda_stream)
         mask_ptrs = [C.c_void_p(t.data_ptr()) for t in d_masks]
         all_ptrs = [C.c_void_p(t.data_ptr()) for t in d_alls]
+        cnt_ptrs = [C.c_void_p(t.data_ptr()) for t in d_cnts]
 
         def gather(slot):
             if lib.mvk_gather_mask_dev(comm, mask_ptrs[slot], words, all_ptrs[slot], side_handle) != 0:
@@ -610,7 +611,18 @@ def main():
         def gather(slot):
             dist.all_gather_into_tensor(d_alls[slot], d_masks[slot])   # (current stream = side; the host does not block)
 
+    def step_mvk(k):
+        # the same step with the exchange issued by ONE library call (event, all-gather, count, event: csrc/mvk_dist.cpp)
+        # and one host wait per refill: three ctypes calls per step, nothing of torch in the loop
+        slot = k % n_slot
+        lib.mvk_exchange_wait(comm, slot)
+        run_batch(d_masks[slot])
+        if lib.mvk_exchange_masks_dev(comm, slot, mask_ptrs[slot], words, all_ptrs[slot], cnt_ptrs[slot], main_handle, side_handle) != 0:
+            raise SystemExit("mvk_exchange_masks_dev: " + lib.mvk_last_error().decode())
+
     def step(k, ev=None):
+        if comm is not None and ev is None:
+            return step_mvk(k)
         slot = k % n_slot
         if exchange and used[slot]:   # this set's last exchange (step k-2) must be through before it is refilled
             # a host wait, not a stream dependency: the exchange of two steps ago has long finished, and a wait in the
@@ -630,6 +642,8 @@ def main():
             used[slot] = True
 
     def drain():
+        if comm is not None:
+            lib.mvk_exchange_wait(comm, -1)
         for slot in range(n_slot):
             if exchange and used[slot]:
                 main_stream.wait_event(done[slot])

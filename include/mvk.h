@@ -353,6 +353,11 @@ int mvk_mask_count_dev(const uint64_t* d_mask, size_t n_bits, uint64_t* d_count,
  *                        with their GLOBAL sample index (local index + index_offset, ties -> smallest index); one
  *                        ncclAllGather of 104 bytes per rank + a host merge; blocks until `stream` has delivered it
  *   mvk_merge_stats      that merge alone, on the host (records that travelled by another channel)
+ *   mvk_exchange_masks_dev  one step's whole exchange in one host call, shaped for a loop that overlaps it with the
+ *                        next steps' kernels: waits (by event, on the device) for `producer_stream`, all-gathers the
+ *                        shard on `exchange_stream`, counts the valid bits of the gathered words into *d_count there
+ *                        (nullable), and marks buffer set `slot` (0..7) busy; mvk_exchange_wait(slot) blocks the host
+ *                        until that set's exchange is through (slot -1: all sets) -- call it before refilling the set
  * Collectives are enqueued on `stream`; a communicator serves one stream at a time. */
 #define MVK_COMM_ID_BYTES 128
 typedef struct mvk_comm mvk_comm;
@@ -366,6 +371,9 @@ int mvk_comm_world(const mvk_comm* comm);
 int mvk_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi, size_t* words_per_rank);
 int mvk_gather_mask_dev(mvk_comm* comm, const uint64_t* d_shard, size_t words_per_rank, uint64_t* d_all, void* stream);
 int mvk_allreduce_count_dev(mvk_comm* comm, uint64_t* d_count, size_t n_counts, void* stream);
+int mvk_exchange_masks_dev(mvk_comm* comm, int slot, const uint64_t* d_shard, size_t words_per_rank, uint64_t* d_all,
+                           uint64_t* d_count, void* producer_stream, void* exchange_stream);
+int mvk_exchange_wait(mvk_comm* comm, int slot);
 int mvk_allreduce_stats(mvk_comm* comm, const mvk_stats* local, uint64_t index_offset, mvk_stats* global, void* stream);
 int mvk_merge_stats(const mvk_stats* locals, const uint64_t* offsets, int world, mvk_stats* global);
 

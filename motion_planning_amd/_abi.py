@@ -194,6 +194,8 @@ PROTOTYPES.update({
     "mvk_shard_range": (ip, [sz, ip, ip, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "mvk_gather_mask_dev": (ip, [vp, vp, sz, vp, vp]),
     "mvk_allreduce_count_dev": (ip, [vp, vp, sz, vp]),
+    "mvk_exchange_masks_dev": (ip, [vp, ip, vp, sz, vp, vp, vp, vp]),
+    "mvk_exchange_wait": (ip, [vp, ip]),
     "mvk_allreduce_stats": (ip, [vp, C.POINTER(Stats), C.c_uint64, C.POINTER(Stats), vp]),
     "mvk_merge_stats": (ip, [C.POINTER(Stats), C.POINTER(C.c_uint64), ip, C.POINTER(Stats)]),
 })

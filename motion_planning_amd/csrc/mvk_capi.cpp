@@ -1133,7 +1133,8 @@ extern "C" int mvk_is_valid_mask_noalloc_dev(mvk_ctx* c, const double* d_soa, si
   c->stats_valid = false;
   if (int rc = enter_stream(c, s)) return rc;
   // the array keeps the last call's contents (any ctx of this GPU): the counters must start at zero
-  HIP_TRY(hipMemsetAsync(base, 0, kStaticCounterSetBytes, s));
+  if (const int ez = launch_zero_words(reinterpret_cast<uint32_t*>(base), kStaticCounterSetBytes / sizeof(uint32_t), s))
+    return fail(MVK_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(ez)));
   // (under graph capture the profiling events would be recorded into the graph: left out)
   const bool timed = c->profiling && !stream_capturing(s);
   const int e = launch_eval(a, c->model.robot_type, c->model.n_rotor, false, s, timed ? c->ev : nullptr);

@@ -80,9 +80,14 @@ static_assert(sizeof(StatsRec) == 13 * 8, "StatsRec is exchanged as 13 64-bit wo
 
 }  // namespace
 
+constexpr int kExchangeSlots = 8;
+
 struct mvk_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
+  // mvk_exchange_masks_dev: per slot, "the producer's mask is ready" and "this slot's exchange is through"
+  hipEvent_t ev_ready[kExchangeSlots] = {}, ev_done[kExchangeSlots] = {};
+  bool slot_used[kExchangeSlots] = {};
   // staging of the statistics exchange: world records on the device, pinned on the host (made once, here)
   StatsRec* d_rec = nullptr;
   StatsRec* h_rec = nullptr;
@@ -124,6 +129,13 @@ extern "C" int mvk_comm_create(const unsigned char* id, int rank, int world, int
     (void)mvk_comm_destroy(c);
     return fail(MVK_ERR_HIP, "mvk_comm_create: staging buffers");
   }
+  for (int k = 0; k < kExchangeSlots; ++k)
+    if (hipEventCreateWithFlags(&c->ev_ready[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)mvk_comm_destroy(c);
+      return fail(MVK_ERR_HIP, "mvk_comm_create: events");
+    }
   *out = c;
   return MVK_OK;
 }
@@ -131,6 +143,10 @@ extern "C" int mvk_comm_create(const unsigned char* id, int rank, int world, int
 extern "C" int mvk_comm_destroy(mvk_comm* c) {
   if (!c) return MVK_OK;
   (void)hipSetDevice(c->device);
+  for (int k = 0; k < kExchangeSlots; ++k) {
+    if (c->ev_ready[k]) (void)hipEventDestroy(c->ev_ready[k]);
+    if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+  }
   if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
   if (c->d_rec) (void)hipFree(c->d_rec);
   if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -156,6 +172,37 @@ extern "C" int mvk_gather_mask_dev(mvk_comm* c, const uint64_t* d_shard, size_t 
   if (words_per_rank == 0) return MVK_OK;
   HIPD_TRY(hipSetDevice(c->device));
   RCCL_TRY(rccl().AllGather(d_shard, d_all, words_per_rank, ncclUint64, c->comm, static_cast<hipStream_t>(stream)));
+  return MVK_OK;
+}
+
+// One step's exchange in one call, overlapped with the next steps' kernels: the mask produced on `producer_stream`
+// is all-gathered on `exchange_stream` once it is ready (an event, not a host wait), and the valid count of the whole
+// job is taken from the gathered words there (every rank itself: no second collective).  `slot` (0 .. 7) names the
+// caller's buffer set; mvk_exchange_wait(slot) is the host wait before that set is refilled.
+extern "C" int mvk_exchange_masks_dev(mvk_comm* c, int slot, const uint64_t* d_shard, size_t words_per_rank, uint64_t* d_all,
+                                      uint64_t* d_count, void* producer_stream, void* exchange_stream) {
+  if (!c || !d_shard || !d_all || slot < 0 || slot >= kExchangeSlots) return fail(MVK_ERR_INVALID_ARG, "mvk_exchange_masks_dev: bad argument");
+  if (words_per_rank == 0) return MVK_OK;
+  hipStream_t ps = static_cast<hipStream_t>(producer_stream), xs = static_cast<hipStream_t>(exchange_stream);
+  if (ps != xs) {
+    HIPD_TRY(hipEventRecord(c->ev_ready[slot], ps));
+    HIPD_TRY(hipStreamWaitEvent(xs, c->ev_ready[slot], 0));
+  }
+  RCCL_TRY(rccl().AllGather(d_shard, d_all, words_per_rank, ncclUint64, c->comm, xs));
+  if (d_count)
+    if (int rc = mvk_mask_count_dev(d_all, static_cast<size_t>(c->world) * words_per_rank * 64, d_count, exchange_stream)) return rc;
+  HIPD_TRY(hipEventRecord(c->ev_done[slot], xs));
+  c->slot_used[slot] = true;
+  return MVK_OK;
+}
+
+extern "C" int mvk_exchange_wait(mvk_comm* c, int slot) {
+  if (!c || slot < -1 || slot >= kExchangeSlots) return fail(MVK_ERR_INVALID_ARG, "mvk_exchange_wait: bad argument");
+  for (int k = slot < 0 ? 0 : slot; k < (slot < 0 ? kExchangeSlots : slot + 1); ++k)
+    if (c->slot_used[k]) {
+      HIPD_TRY(hipEventSynchronize(c->ev_done[k]));
+      c->slot_used[k] = false;
+    }
   return MVK_OK;
 }
 

@@ -249,6 +249,7 @@ int static_scratch_for_current_device(int device, void** ptr);
 int launch_eval(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream, void* events);
 int launch_avoid(const EvalArgs& a, int robot_type, int n_links, void* stream);
 int launch_flag_small(const EvalArgs& a, int robot_type, int n_links, bool edge_mode, void* stream);
+int launch_zero_words(uint32_t* p, uint64_t n_words, void* stream);
 int launch_edge_init(int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint64_t n_edges, void* stream);
 int launch_edge_finish(const int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint8_t* ok,
                        uint64_t n_edges, void* stream);

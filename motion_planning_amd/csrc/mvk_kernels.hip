@@ -448,7 +448,16 @@ struct Shape {
   static constexpr int rotor_seg(int i) { return kGimbal ? 2 * i : i; }
   // waves per SIMD the screen kernel is compiled for (caps its VGPRs at 512 / waves): the walk-1
   // arithmetic offers the scheduler more independent chains than pay off in registers
-  static constexpr int kScreenWaves = (!kGimbal && NL <= 4) ? 4 : 3;  // (NL = 8: see the LDS budget in screen_kernel)
+#ifndef MVK_SW_H4
+#define MVK_SW_H4 4
+#endif
+#ifndef MVK_SW_H8
+#define MVK_SW_H8 3
+#endif
+#ifndef MVK_SW_D
+#define MVK_SW_D 3
+#endif
+  static constexpr int kScreenWaves = kGimbal ? MVK_SW_D : NL <= 4 ? MVK_SW_H4 : NL >= 8 ? MVK_SW_H8 : 3;  // (NL = 8: see the LDS budget in screen_kernel)
 };
 
 #ifndef MVK_LIST_CAP
@@ -4785,6 +4794,12 @@ avoid_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevE
 // ------------------------------------------------------------------------
 // small helper kernels
 // ------------------------------------------------------------------------
+// the no-allocation entry point's counter set must start at zero; a kernel, not hipMemsetAsync: captured into a
+// graph the memset node did not take effect on replay (tests/test_zz_no_alloc.py: a few verdicts differed from the
+// second launch of the graph on), a kernel node does
+__global__ void zero_words_kernel(uint32_t* p, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
 __global__ void edge_init_kernel(int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint64_t n) {
   const uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e < n) {
@@ -4981,6 +4996,12 @@ int launch_avoid(const EvalArgs& a, int robot_type, int n_links, void* stream) {
   else if (robot_type == MVK_ROBOT_HYDRUS && n_links == 8) hipLaunchKernelGGL((avoid_kernel<MVK_ROBOT_HYDRUS, 8>), g, b, 0, s, a, a.model, a.extras, a.obs);
   else if (robot_type == MVK_ROBOT_DRAGON && n_links == 4) hipLaunchKernelGGL((avoid_kernel<MVK_ROBOT_DRAGON, 4>), g, b, 0, s, a, a.model, a.extras, a.obs);
   else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+int launch_zero_words(uint32_t* p, uint64_t n_words, void* stream) {
+  if (n_words == 0) return hipSuccess;
+  const unsigned blocks = static_cast<unsigned>(std::min<uint64_t>((n_words + 255) / 256, 64));
+  hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, static_cast<uint32_t>(n_words));
   return hipGetLastError();
 }
 int launch_edge_init(int32_t* first_invalid, const int32_t* nd, int32_t nd_uniform, uint64_t n_edges, void* stream) {

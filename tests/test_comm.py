@@ -95,6 +95,17 @@ def test_communicator_of_one_rank_over_rccl():
         assert torch.equal(full, mask)
         flags = eng.is_valid_batch(w.soa, w.layout)["flags"]
         assert int(cnt[0]) == int(flags.sum()) and 0 < int(cnt[0]) < n
+        # the one-call form of the step's exchange: event on the producer stream, all-gather + count on another
+        side = torch.cuda.Stream(device=dev)
+        for slot in (0, 3, 0):
+            full.fill_(-1)
+            cnt.zero_()
+            eng.is_valid_mask_dev(d, w.layout, mask)
+            assert lib.mvk_exchange_masks_dev(comm, slot, mask.data_ptr(), per, full.data_ptr(), cnt.data_ptr(), s, side.cuda_stream) == 0, lib.mvk_last_error()
+            assert lib.mvk_exchange_wait(comm, slot) == 0
+            assert torch.equal(full, mask) and int(cnt[0]) == int(flags.sum())
+        assert lib.mvk_exchange_wait(comm, -1) == 0
+        assert lib.mvk_exchange_masks_dev(comm, 8, mask.data_ptr(), per, full.data_ptr(), None, s, s) == A.ERR_INVALID_ARG
         # statistics of a full evaluation: the exchange of one rank returns them with the offset applied
         eng.eval_batch(w.soa[:, :4096], w.layout)
         loc = A.Stats()
