@@ -449,7 +449,7 @@ struct Shape {
   // waves per SIMD the screen kernel is compiled for (caps its VGPRs at 512 / waves): the walk-1
   // arithmetic offers the scheduler more independent chains than pay off in registers
 #ifndef MVK_SW_H4
-#define MVK_SW_H4 4
+#define MVK_SW_H4 3
 #endif
 #ifndef MVK_SW_H8
 #define MVK_SW_H8 3
