@@ -509,6 +509,9 @@ def main():
     ap.add_argument("--exchange", default="mvk", choices=["mvk", "torch"],
                     help="who issues the per-step mask all-gather: the library's C ABI (mvk_gather_mask_dev, RCCL called from "
                          "libmvk.so; default) or torch.distributed (diagnostics)")
+    ap.add_argument("--overlap-exchange", action="store_true", help="issue the exchange on a second stream (mvk_exchange_masks_dev)")
+    ap.add_argument("--count-every-step", action="store_true", help="count the valid bits of the gathered masks every step, not only after the last")
+    ap.add_argument("--slots", type=int, default=4, help="exchange buffer sets: how many steps the host may run ahead of the exchange")
     ap.add_argument("--cold-steps", type=int, default=20, help="N = 1: timed steps of the from-cold pass before the pre-warm (0: skip)")
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="one rank: run the step's RCCL exchange (a group of one) exactly as the N > 1 path issues it")
@@ -572,7 +575,7 @@ def main():
     # Four sets of exchange buffers: the mask all-gather and the count of step k run on the exchange stream while the
     # kernels of steps k+1 .. k+3 fill the other sets (collectives overlapped with compute; the host waits for the
     # exchange of step k-4 before it refills a set, which by then has long finished).
-    n_slot = 4 if exchange else 1
+    n_slot = max(1, min(8, args.slots)) if exchange else 1
     d_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(n_slot)]
     d_alls = [torch.zeros(world * words, dtype=torch.int64, device=dev) for _ in range(n_slot)] if exchange else None
     d_cnts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n_slot)]
@@ -612,13 +615,26 @@ def main():
             dist.all_gather_into_tensor(d_alls[slot], d_masks[slot])   # (current stream = side; the host does not block)
 
     def step_mvk(k):
-        # the same step with the exchange issued by ONE library call (event, all-gather, count, event: csrc/mvk_dist.cpp)
-        # and one host wait per refill: three ctypes calls per step, nothing of torch in the loop
+        # The step with the exchange issued by the library (csrc/mvk_dist.cpp), nothing of torch in the loop.
+        # Default: the all-gather follows the kernels on the launch stream (two ctypes calls per step).  Measured on one
+        # GPU with a communicator of one rank (profiles/r03/exchange_rehearsal.txt): 143.9 us per step against 138.0
+        # without exchange; handing the exchange to a second stream (--overlap-exchange: event, all-gather, count, event,
+        # in mvk_exchange_masks_dev) costs MORE there, 154.8 us -- the event marker in the launch stream and the
+        # concurrent kernels outweigh the 6 us they hide -- and the valid count of the whole job, taken from the gathered
+        # words by a kernel per step (--count-every-step), another 7 us: it is taken once, after the last step.
         slot = k % n_slot
-        lib.mvk_exchange_wait(comm, slot)
-        run_batch(d_masks[slot])
-        if lib.mvk_exchange_masks_dev(comm, slot, mask_ptrs[slot], words, all_ptrs[slot], cnt_ptrs[slot], main_handle, side_handle) != 0:
-            raise SystemExit("mvk_exchange_masks_dev: " + lib.mvk_last_error().decode())
+        if args.overlap_exchange:
+            lib.mvk_exchange_wait(comm, slot)
+            run_batch(d_masks[slot])
+            rc = lib.mvk_exchange_masks_dev(comm, slot, mask_ptrs[slot], words, all_ptrs[slot],
+                                            cnt_ptrs[slot] if args.count_every_step else None, main_handle, side_handle)
+        else:
+            run_batch(d_masks[slot])
+            rc = lib.mvk_gather_mask_dev(comm, mask_ptrs[slot], words, all_ptrs[slot], main_handle)
+            if rc == 0 and args.count_every_step:
+                rc = lib.mvk_mask_count_dev(all_ptrs[slot], world * words * 64, cnt_ptrs[slot], main_handle)
+        if rc != 0:
+            raise SystemExit("exchange: " + lib.mvk_last_error().decode())
 
     def step(k, ev=None):
         if comm is not None and ev is None:
@@ -749,9 +765,14 @@ def main():
         }
         if exchange:
             last = (args.steps - 1) % n_slot
+            if comm is not None and not args.count_every_step:
+                eng.mask_count_dev(d_alls[last], world * words * 64, d_cnts[last], stream=main_stream)
+                torch.cuda.synchronize()
             out["valid_total_last_step"] = int(d_cnts[last].item())   # all-reduced over ranks (mvk_mask_count_dev + RCCL sum)
             out["exchange_by"] = "libmvk.so (mvk_gather_mask_dev -> ncclAllGather, csrc/mvk_dist.cpp)" if comm is not None else "torch.distributed"
-            out["exchange"] = "per step: all-gather of the packed masks, valid count of the whole job from the gathered words on every rank; overlapped with the next step's kernels"
+            out["exchange"] = ("per step: all-gather of the packed masks (RCCL); " +
+                               ("on a second stream, overlapped with the next step's kernels; " if args.overlap_exchange or comm is None else "on the launch stream behind the kernels; ") +
+                               ("valid count of the whole job from the gathered words every step" if args.count_every_step or comm is None else "valid count of the whole job from the gathered words after the last step"))
             out["exchange_ms"] = exchange_ms   # one exchange alone (max over ranks): what the overlap hides
             out["host_issue_ms_per_step"] = t_issued / args.steps * 1e3   # rank 0's host loop: launches + exchange calls
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
