@@ -216,11 +216,15 @@ void derive_extras(const mvk_model* m, DevExtras* x) {
     for (int k = 0; k < m->n_seg; ++k) mass += m->seg_mass[k];
     x->inv_mass = 1.0 / mass;
   }
+  // chain order of the primitives: by segment, and within a segment spheres and capsules before boxes.  Their exact
+  // distances are closed forms that lower the running minimum at once, so the boxes of the segment (and everything
+  // after) meet a tighter bound and fewer box pairs reach the 24-edge exact stage; results do not depend on the order.
   int at = 0;
   for (int k = 0; k < m->n_seg; ++k) {
     x->seg_prim_begin[k] = at;
-    for (int q = 0; q < m->n_prim; ++q)
-      if (m->prim_seg[q] == k) x->prim_order[at++] = q;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int q = 0; q < m->n_prim; ++q)
+        if (m->prim_seg[q] == k && (m->prim_type[q] == MVK_PRIM_BOX) == (pass == 1)) x->prim_order[at++] = q;
   }
   for (int k = m->n_seg; k <= MVK_MAX_SEG; ++k) x->seg_prim_begin[k] = at;
   // bounding sphere of each segment's primitives (level-1 cull) and the robot's reach
@@ -262,8 +266,8 @@ void derive_extras(const mvk_model* m, DevExtras* x) {
     T.axis = m->seg_axis[k];
     T.joint = m->seg_joint[k];
     T.np = 0;
-    for (int q = 0; q < m->n_prim; ++q)
-      if (m->prim_seg[q] == k && T.np < kSegPrimMax) {
+    for (int oi = x->seg_prim_begin[k]; oi < x->seg_prim_begin[k + 1]; ++oi)  // (the same order as prim_order: slot j <-> prim_order[begin + j])
+      if (const int q = x->prim_order[oi]; T.np < kSegPrimMax) {
         for (int a = 0; a < 3; ++a) {
           T.prim_pos[T.np][a] = m->prim_pos[q][a];
           T.gimbal_pos[T.np][a] = m->prim_frame[q] == MVK_FRAME_SEG ? 0.0 : m->rotor_pos[m->prim_rotor[q]][a];
@@ -326,6 +330,53 @@ void derive_extras(const mvk_model* m, DevExtras* x) {
         x->prim_inner[q] = std::fmin(d[0], std::fmin(d[1], d[2]));
     }
   }
+  // Groups of co-located primitives (distance kernel: one broadphase per group).  Consecutive primitives of a segment
+  // in drain order join the current group while their centre stays within kGroupTol of its first member's centre in
+  // every configuration: |anchor - anchor_first| + the swing of a primitive on a gimbal frame about its anchor.
+  {
+    const bool off = std::getenv("MVK_NO_PRIM_GROUPS") && std::getenv("MVK_NO_PRIM_GROUPS")[0] == '1';
+    const double kGroupTol = 0.08;
+    auto anchor_of = [&](int q) { return m->prim_frame[q] == MVK_FRAME_SEG ? m->prim_pos[q] : m->rotor_pos[m->prim_rotor[q]]; };
+    auto swing_of = [&](int q) {
+      const double* v = m->prim_pos[q];
+      return m->prim_frame[q] == MVK_FRAME_SEG ? 0.0 : std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    };
+    auto apart = [&](int q, int l) {  // how far q's centre can be from l's, in any configuration
+      if (q == l) return 0.0;
+      const double *a = anchor_of(q), *b = anchor_of(l);
+      return std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2])) + swing_of(q) + swing_of(l);
+    };
+    int ng = 0;
+    x->grp_rb_max = 0.0;
+    for (int k = 0; k < m->n_seg; ++k) {
+      x->seg_grp_begin[k] = ng;
+      int first = -1;
+      for (int oi = x->seg_prim_begin[k]; oi < x->seg_prim_begin[k + 1]; ++oi) {
+        const int q = x->prim_order[oi];
+        if (first < 0 || off || apart(q, first) > kGroupTol) {  // a new group, q opens it
+          x->grp_begin[ng++] = oi;
+          first = q;
+        }
+      }
+    }
+    x->grp_begin[ng] = x->seg_prim_begin[m->n_seg];
+    // the broadphase is centred on the member that needs the smallest radius to contain all of them (the largest
+    // member, as a rule: its own list is then no longer than without the group)
+    for (int g = 0; g < ng; ++g) {
+      double best = INFINITY;
+      for (int li = x->grp_begin[g]; li < x->grp_begin[g + 1]; ++li) {
+        double r = 0.0;
+        for (int oi = x->grp_begin[g]; oi < x->grp_begin[g + 1]; ++oi)
+          r = std::fmax(r, x->prim_bound[x->prim_order[oi]] + apart(x->prim_order[oi], x->prim_order[li]));
+        if (r < best) { best = r; x->grp_lead[g] = li; }
+      }
+      x->grp_rb[g] = x->grp_begin[g + 1] - x->grp_begin[g] == 1 ? best : best * (1.0 + 1e-12) + 1e-12;
+    }
+    for (int k = m->n_seg; k <= MVK_MAX_SEG; ++k) x->seg_grp_begin[k] = ng;
+    for (int g = ng; g <= MVK_MAX_PRIM; ++g) x->grp_begin[g] = x->seg_prim_begin[m->n_seg];
+    for (int g = 0; g < ng; ++g) x->grp_rb_max = std::fmax(x->grp_rb_max, x->grp_rb[g]);
+    x->n_grp = off ? 0 : ng;
+  }
 }
 
 int boxes_to_obs(const mvk_box* boxes, size_t n, std::vector<DevObs>& host) {
@@ -367,7 +418,7 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
   if (n < 64) return MVK_OK;
   // diagnostics (profiles/full_time.py, tests): keep the sweep over all boxes for scenes set from now on
   if (const char* off = std::getenv("MVK_NO_DISTANCE_GRID")) if (off[0] == '1') return MVK_OK;
-  double rb = 0.0;
+  double rb = c->extras.grp_rb_max;  // (>= every primitive's bounding radius: the distance kernel asks about group leaders)
   for (int q = 0; q < c->model.n_prim; ++q) rb = std::fmax(rb, c->extras.prim_bound[q]);
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (size_t i = 0; i < n; ++i)

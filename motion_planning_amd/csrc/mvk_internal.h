@@ -68,6 +68,15 @@ struct DevExtras {
   double prim_bound[MVK_MAX_PRIM];  // radius about the primitive origin containing it
   double prim_inner[MVK_MAX_PRIM];  // radius about the origin contained in it
   int32_t seg_prim_begin[MVK_MAX_SEG + 1];  // primitives sorted by segment
+  // groups of co-located primitives of a segment (consecutive in chain order): the distance kernel runs ONE broadphase
+  // per group about its leader's centre with radius grp_rb (contains every member) and every member's narrowphase over
+  // that list.  n_grp == 0: one primitive at a time (MVK_NO_PRIM_GROUPS=1, diagnostics / identity tests)
+  int32_t n_grp;
+  int32_t grp_begin[MVK_MAX_PRIM + 1];
+  int32_t grp_lead[MVK_MAX_PRIM];  // index into prim_order of the member the broadphase is centred on
+  int32_t seg_grp_begin[MVK_MAX_SEG + 1];
+  double grp_rb[MVK_MAX_PRIM];
+  double grp_rb_max;  // >= every prim_bound: the radius the distance grids and the far grid are built for
   int32_t prim_order[MVK_MAX_PRIM];
   double seg_sph[MVK_MAX_SEG][4];  // per segment: sphere (centre in the segment frame, radius) holding its primitives
   double reach;                    // bound on the distance of any primitive point from the root origin

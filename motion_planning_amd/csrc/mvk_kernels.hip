@@ -2093,6 +2093,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
   p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
   double mind = INFINITY;
   const bool use_grid = A.dgrid.start != nullptr;
+  const bool grouped = use_grid && X->n_grp > 0;  // (the sweep over all boxes of small scenes keeps one primitive at a time)
   const bool f32_safe = fmax(fabs(pos[0]), fmax(fabs(pos[1]), fabs(pos[2]))) + X->reach <= A.f32_range;
   // with the distance grid, a first walk over the chain bounds the state's distance from above: the smallest
   // centre-to-listed-box distance over all primitives.  The second walk then collects, per primitive, only the
@@ -2111,7 +2112,6 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
     const bool on = live && f32_safe;
 #pragma unroll
     for (int sl = 0; sl < kUpperSlots; ++sl) up_bits[sl * kBlock + tid] = 0x7F800000u;  // +inf
-    double rb_max = 0.0;
     // first walk: per primitive the smallest centre distance over its cell's list (fp32), through the ring
     auto upper_walk = [&](bool all_boxes, bool who) {  // (all_boxes: kept for experiments; the walk below uses the lists)
 #pragma unroll
@@ -2120,16 +2120,15 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
 #pragma unroll 1
       for (int k = 0; k < S::kSeg; ++k) {
         if (k > 0) advance_frame(M, sm, tid, k, R, p);
-        const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
+        const int gfirst = grouped ? X->seg_grp_begin[k] : X->seg_prim_begin[k], glast = grouped ? X->seg_grp_begin[k + 1] : X->seg_prim_begin[k + 1];
 #pragma unroll 1
-        for (int qi = pb; qi < pe; ++qi) {
-          const int q = X->prim_order[qi];
+        for (int g = gfirst; g < glast; ++g) {  // the group's leader stands for its members (its centre lies inside it)
+          const int q = X->prim_order[grouped ? X->grp_lead[g] : g];
           double pc[3];
           prim_pose<S::kGimbal, false>(M, q, R, p, pc, nullptr);
-          rb_max = fmax(rb_max, X->prim_bound[q]);
           unsigned gb = 0, ge = groups_all;
           if (!all_boxes) grid_cell(A.dgrid, pc, who, gb, ge);
-          dist_push(sm, who, pc, gb, ge, static_cast<unsigned>(qi < kUpperSlots ? qi : kUpperSlots - 1), all_boxes ? kRangeAll : kRangeCell, 0.0f, head, qn);
+          dist_push(sm, who, pc, gb, ge, static_cast<unsigned>(g < kUpperSlots ? g : kUpperSlots - 1), all_boxes ? kRangeAll : kRangeCell, 0.0f, head, qn);
 #pragma unroll 1
           while (qn >= 64u) dist_pop<false>(A, obsf, sm, head, qn);
         }
@@ -2152,19 +2151,23 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
 #pragma unroll 1
   for (int k = 0; k < S::kSeg; ++k) {
     if (k > 0) advance_frame(M, sm, tid, k, R, p);
-    const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
+    const int gfirst = grouped ? X->seg_grp_begin[k] : X->seg_prim_begin[k], glast = grouped ? X->seg_grp_begin[k + 1] : X->seg_prim_begin[k + 1];
 #pragma unroll 1
-    for (int qi = pb; qi < pe; ++qi) {
-      const int q = X->prim_order[qi];
-      const int type = M->prim_type[q];
-      double pc[3], PR[9];
-      prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
-      const double rb = X->prim_bound[q];
-      const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+    for (int g = gfirst; g < glast; ++g) {
+      // One broadphase per GROUP of co-located primitives (a link's bar and its propeller protector; a link's pipe and
+      // its two gimbal modules): the candidates are collected about the leader's centre with a radius that contains
+      // every member (DevExtras::grp_rb), then every member runs its narrowphase over that one list.
+      const int qb = grouped ? X->grp_begin[g] : g, qe = grouped ? X->grp_begin[g + 1] : g + 1;
+      const bool single = qe - qb == 1;
+      double pc[3];
+      prim_pose<S::kGimbal, false>(M, X->prim_order[grouped ? X->grp_lead[g] : g], R, p, pc, nullptr);
+      const double rb = grouped ? X->grp_rb[g] : X->prim_bound[X->prim_order[qb]];
+      const int qi = g;  // (the slot of the first walk's bound)
 
       // -- broadphase --------------------------------------------------------
       PROF_T0(t_bp);
-      const bool sphere = type == MVK_PRIM_SPHERE;
+      const bool sphere = single && M->prim_type[X->prim_order[qb]] == MVK_PRIM_SPHERE;
+      const double d0_lead = M->prim_dim[X->prim_order[qb]][0];
       int cnt = 0;
       bool scan = live;  // lanes whose candidates come from the sweep over all boxes
       bool swept = false;
@@ -2223,7 +2226,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
         sweep_for_lanes(A, obs, sm, slow, pc, rb, mind, b2, c2);
         if (slow) {
           scan = true;
-          if (sphere) mind = fmin(mind, sqrt(b2) - d0);  // exact for a sphere
+          if (sphere) mind = fmin(mind, sqrt(b2) - d0_lead);  // exact for a sphere (a group of one)
           else cnt = c2;
         }
       } else if (__any(scan)) {
@@ -2241,7 +2244,7 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
 #pragma unroll 2
         for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
         if (sphere) {
-          mind = fmin(mind, sqrt(best2) - d0);  // exact for a sphere
+          mind = fmin(mind, sqrt(best2) - d0_lead);  // exact for a sphere
         } else {
           // pass 2: keep pairs whose lower bound (centre distance - bounding radius)
           // can still undercut the running minimum, and every possibly-touching pair
@@ -2256,6 +2259,22 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
           }
         }
       }
+      PROF_CLK(1, t_bp);
+      const int cnt_g = cnt;
+      const bool scan_g = scan;
+#pragma unroll 1
+      for (int qm = qb; qm < qe; ++qm) {
+      const int q = X->prim_order[qm];
+      const int type = M->prim_type[q];
+      double PR[9];
+      prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);  // (pc: this member's own centre from here on)
+      const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+      cnt = cnt_g;
+      scan = scan_g;
+      // a member of a group of several walks the group's list, which reaches farther than its own would: a candidate
+      // whose centre distance minus the member's own bounding radius cannot undercut the running minimum is dropped
+      // before the separating-axis bound (it could not lower the minimum, so the result keeps its bits)
+      const double own = single ? INFINITY : X->prim_bound[q];
       // -- narrowphase drain: kind is wave-uniform, list length is per lane ---
       // a lane with more candidates than its list holds walks its grid cell's whole list instead (complete by
       // construction), or every box of the scene when its candidates came from a sweep
@@ -2269,7 +2288,6 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
 #ifdef MVK_PROF_COUNTS
       PROF_LANES(30, live); PROF_LANES(31, live && scan); PROF_LANES(32, live && overflow); PROF_SUM(33, live ? cnt : 0);
 #endif
-      PROF_CLK(1, t_bp);
       PROF_T0(t_dr);
       if (type == MVK_PRIM_BOX) {
         // The exact box-box separation (24 edge-to-box distances) costs ~30x the separating-axis bound, and
@@ -2374,12 +2392,15 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
               const int ob = sm.list[e * kBlock + wave_tid + src];
               const DevObs& O = obs[ob];
               to_box_frame(O, spc, t);
-              box_rel(O, sPR, Rr);
               h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
               const double cut = ord_val(sm.mres[src]) + kSatSlack;
-              g = box_box_sat<true>(t, Rr, a, h, cut);
-              if (g <= 0.0) __hip_atomic_fetch_min(&sm.mres[src], ord_key(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-              else need = g < cut;
+              const double reach_m = own + fmax(cut, 0.0);
+              if (single || point_box_dist2(t, h) <= reach_m * reach_m) {
+                box_rel(O, sPR, Rr);
+                g = box_box_sat<true>(t, Rr, a, h, cut);
+                if (g <= 0.0) __hip_atomic_fetch_min(&sm.mres[src], ord_key(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                else need = g < cut;
+              }
               if (need) __hip_atomic_fetch_min(&sm.gmin[src], static_cast<unsigned long long>(__double_as_longlong(g)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2404,11 +2425,14 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
             if (ob != kGridNone) {
               const DevObs& O = obs[ob];
               to_box_frame(O, pc, t);
-              box_rel(O, PR, Rr);
               h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
-              const double g = box_box_sat<true>(t, Rr, a, h, mind + kSatSlack);
-              if (g <= 0.0) mind = fmin(mind, g);
-              else need = g < mind + kSatSlack;
+              const double reach_m = own + fmax(mind + kSatSlack, 0.0);
+              if (single || point_box_dist2(t, h) <= reach_m * reach_m) {
+                box_rel(O, PR, Rr);
+                const double g = box_box_sat<true>(t, Rr, a, h, mind + kSatSlack);
+                if (g <= 0.0) mind = fmin(mind, g);
+                else need = g < mind + kSatSlack;
+              }
             }
             ++e;
           }
@@ -2478,11 +2502,17 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
             const DevObs O = obs[ob];
             double t[3];
             to_box_frame(O, pc, t);
-            mind = fmin(mind, sphere ? sqrt(point_box_dist2(t, O.h)) - d0 : narrow<true>(type, PR, d0, d1, d2, O, t, mind));
+            if (type == MVK_PRIM_SPHERE) {
+              mind = fmin(mind, sqrt(point_box_dist2(t, O.h)) - d0);
+            } else {
+              const double reach_m = own + fmax(mind + kSatSlack, 0.0);
+              if (single || point_box_dist2(t, O.h) <= reach_m * reach_m) mind = fmin(mind, narrow<true>(type, PR, d0, d1, d2, O, t, mind));
+            }
           }
         }
       }
       PROF_CLK(2, t_dr);
+      }  // members
     }
   }
   PROF_ACC_FLUSH(20);
