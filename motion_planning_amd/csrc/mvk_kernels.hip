@@ -2319,8 +2319,15 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
           // into the owner's minimum
           auto run_exact = [&](bool want, int src, const double Rr[9], const double t[3], const double h[3]) {
             unsigned long long pend = __ballot(want);
+            PROF_T0(t_ex);
+#ifdef MVK_PROF_COUNTS
+            PROF_SUM(34, want ? 1 : 0);
+#endif
 #pragma unroll 1
             while (pend) {
+#ifdef MVK_PROF_COUNTS
+              PROF_WAVE(35);
+#endif
               const int rank = __popcll(pend & ((1ull << lane) - 1ull));
               const bool mine = want && ((pend >> lane) & 1ull) && rank < kExactBatch;
               const int E = min(static_cast<int>(__popcll(pend)), kExactBatch);
@@ -2365,11 +2372,15 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
               __builtin_amdgcn_wave_barrier();
             }
+            PROF_CLK(3, t_ex);
           };
 #pragma unroll 1
           for (unsigned base = 0; base < T; base += 64u) {
             const unsigned i = base + static_cast<unsigned>(lane);
             const bool act = i < T;
+#ifdef MVK_PROF_COUNTS
+            PROF_WAVE(26);
+#endif
             unsigned lo = 0u, hi = 63u;  // the owner: the first lane whose inclusive count exceeds i
 #pragma unroll
             for (int st = 0; st < 6; ++st) {
@@ -2398,6 +2409,9 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
               if (single || point_box_dist2(t, h) <= reach_m * reach_m) {
                 box_rel(O, sPR, Rr);
                 g = box_box_sat<true>(t, Rr, a, h, cut);
+#ifdef MVK_PROF_COUNTS
+                atomicAdd(&g_prof[27], 1ull);
+#endif
                 if (g <= 0.0) __hip_atomic_fetch_min(&sm.mres[src], ord_key(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 else need = g < cut;
               }
@@ -2495,8 +2509,64 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
           PROF_CLK(3, t_ex);
         }
       } else {
+        // Closed-form primitives (sphere, capsule): the same flat drain without the exact stage -- the wave numbers
+        // the (lane, candidate) pairs through and takes them 64 at a time instead of every lane walking its own list
+        // for as many rounds as the longest of 64 has entries; a distance merges into its owner's minimum with an LDS
+        // atomic on the ordered key (the minimum of the same values: the same bits).
+        const bool flat = use_grid && !__any(live && overflow);
+        if (flat) {
+          const int wave_tid = tid - lane;
+          unsigned incl = static_cast<unsigned>(todo);
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+          }
+          const unsigned T = __shfl(incl, 63);
+          sm.dcnt[lane] = incl;
+          sm.mres[lane] = ord_key(mind);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-        for (int e = 0; __any(e < todo); ++e) {
+          for (unsigned base = 0; base < T; base += 64u) {
+            const unsigned i = base + static_cast<unsigned>(lane);
+            const bool act = i < T;
+            unsigned lo = 0u, hi = 63u;  // the owner: the first lane whose inclusive count exceeds i
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+              const unsigned mid = (lo + hi) >> 1;
+              if (sm.dcnt[mid] > i) hi = mid; else lo = mid + 1u;
+            }
+            const int src = act ? static_cast<int>(lo) : lane;
+            const unsigned e = i - (src > 0 ? sm.dcnt[src - 1] : 0u);
+            double spc[3], sPR[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) spc[c] = __shfl(pc[c], src);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sPR[3 * c + 2] = __shfl(PR[3 * c + 2], src);  // (a capsule's axis: all narrow() reads)
+            if (act) {
+              const int ob = sm.list[e * kBlock + wave_tid + src];
+              const DevObs& O = obs[ob];
+              double t[3];
+              to_box_frame(O, spc, t);
+              const double h[3] = {O.h[0], O.h[1], O.h[2]};
+              const double c2 = point_box_dist2(t, h);
+              double d = INFINITY;
+              if (type == MVK_PRIM_SPHERE) {
+                d = sqrt(c2) - d0;
+              } else {
+                const double reach_m = own + fmax(ord_val(sm.mres[src]) + kSatSlack, 0.0);
+                if (single || c2 <= reach_m * reach_m) d = narrow<true>(type, sPR, d0, d1, d2, O, t, INFINITY);
+              }
+              __hip_atomic_fetch_min(&sm.mres[src], ord_key(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          mind = ord_val(sm.mres[lane]);
+        }
+#pragma unroll 1
+        for (int e = flat ? todo : 0; __any(e < todo); ++e) {
           const int ob = e < todo ? cand(e) : kGridNone;
           if (ob != kGridNone) {
             const DevObs O = obs[ob];

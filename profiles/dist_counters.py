@@ -27,6 +27,7 @@ for name in sys.argv[1:] or ["c2", "c2k", "c3", "c5"]:
     wv = max(b[28], 1)
     print(f"{name} full : per wave, us: model update {b[24] / wv / 100:.1f}, collision {b[25] / wv / 100:.1f} = first walk {b[20] / wv / 100:.1f} + candidates {b[21] / wv / 100:.1f}"
           f" + drain {b[22] / wv / 100:.1f} (of which exact stage {b[23] / wv / 100:.1f}); exact pairs per state {b[34] / n:.2f}, exact rounds per wave {b[35] / wv:.1f}; waves {wv}")
+    print(f"{name} full : flat box drain: rounds of 64 pairs per wave {b[26] / wv:.1f}, separating-axis bounds per state {b[27] / n:.2f}")
     P = w.model.n_prim
     outs = dict(dist=torch.zeros(P, n, dtype=torch.float64, device="cuda"), ok=torch.zeros(n, dtype=torch.uint8, device="cuda"))
     eng.collision_avoidance_batch_dev(d, w.layout, outs)
