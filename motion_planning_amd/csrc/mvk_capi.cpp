@@ -104,7 +104,7 @@ struct mvk_ctx {
   DevExtras extras{};
   mvk_model* d_model = nullptr;
   DevExtras* d_extras = nullptr;
-  Buf obs, obsf, grid_start, grid_items, dgrid_start[2], dgrid_items[2], fgrid_start, fgrid_items;
+  Buf obs, obsf, grid_start, grid_items, dgrid_start[2], dgrid_items[2], dgrid_glb[2], fgrid_start, fgrid_items;
   // flag path hand-off between the screen and the exact stage (see EvalArgs).  Two alternating sets
   // of queue counters: call k appends to set k%2 and zeroes set (k+1)%2, so no memset sits between
   // launches.  Calls on one ctx must therefore be ordered with respect to each other (one stream at a time).
@@ -457,7 +457,9 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
     double slack = std::fmin(std::fmax(dist[(kProbe * pct) / 100], 0.05), 4.0);
     GridHost gh;
     bool built = false;
-    for (int attempt = 0; attempt < 3 && !built; ++attempt, slack *= 0.5) built = build_grid(host.data(), n, rb + slack, gh) == MVK_OK;
+    // lists sorted by the box-to-cell lower bound, so that a walk stops early (diagnostics: MVK_NO_GRID_BOUNDS=1)
+    const bool by_bound = !(std::getenv("MVK_NO_GRID_BOUNDS") && std::getenv("MVK_NO_GRID_BOUNDS")[0] == '1');
+    for (int attempt = 0; attempt < 3 && !built; ++attempt, slack *= 0.5) built = build_grid(host.data(), n, rb + slack, gh, by_bound, 4.0 * static_cast<double>(c->f32_delta)) == MVK_OK;
     if (!built) continue;  // too dense for the grid's budget: the sweep stays
     double mean_len = 0.0;
     for (int i = 0; i < kProbe; ++i) {
@@ -477,6 +479,12 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
     d.pad = 0;
     d.start = static_cast<const uint32_t*>(c->dgrid_start[g].p);
     d.items = static_cast<const uint16_t*>(c->dgrid_items[g].p);
+    d.glb = nullptr;
+    if (!gh.glb.empty()) {
+      if (int rc = c->dgrid_glb[g].reserve(sizeof(float) * (gh.glb.size() + 1))) return rc;
+      HIP_TRY(hipMemcpy(c->dgrid_glb[g].p, gh.glb.data(), sizeof(float) * gh.glb.size(), hipMemcpyHostToDevice));
+      d.glb = static_cast<const float*>(c->dgrid_glb[g].p);
+    }
     c->dgrid_radius[g] = gh.radius;
     if (std::getenv("MVK_DISTANCE_GRID_TRACE"))
       std::fprintf(stderr, "mvk: distance grid %d: radius %.3f (slack %.3f), cell %.3f, %d x %d x %d cells, mean list %.1f of %zu boxes\n",
@@ -1007,7 +1015,7 @@ extern "C" void mvk_destroy(mvk_ctx* c) {
   if (c->order_ev) (void)hipEventDestroy(c->order_ev);
   if (c->d_model) (void)hipFree(c->d_model);
   if (c->d_extras) (void)hipFree(c->d_extras);
-  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start[0], &c->dgrid_items[0], &c->dgrid_start[1], &c->dgrid_items[1], &c->fgrid_start, &c->fgrid_items, &c->queue, &c->queue_rec, &c->queue_counts, &c->refine_list, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
+  Buf* all[] = {&c->obs, &c->obsf, &c->grid_start, &c->grid_items, &c->dgrid_start[0], &c->dgrid_items[0], &c->dgrid_start[1], &c->dgrid_items[1], &c->dgrid_glb[0], &c->dgrid_glb[1], &c->fgrid_start, &c->fgrid_items, &c->queue, &c->queue_rec, &c->queue_counts, &c->refine_list, &c->in_a, &c->in_b, &c->flags, &c->band, &c->mind, &c->margin, &c->det[0], &c->det[1],
                 &c->det[2], &c->det[3], &c->det[4], &c->det[5], &c->nd, &c->ok, &c->first, &c->edge_off,
                 &c->partial, &c->stats_out, &c->full_rec, &c->small_done, &c->av[0], &c->av[1], &c->av[2], &c->av[3], &c->av[4], &c->av[5], &c->av[6]};
   for (Buf* b : all) b->release();

@@ -52,9 +52,10 @@ double cube_box_lower_bound(const DevObs& o, const double ext[3], const double c
 
 }  // namespace
 
-int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g) {
+int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_bound, double pad) {
   g.start.clear();
   g.items.clear();
+  g.glb.clear();
   g.radius = radius;
   for (int k = 0; k < 3; ++k) { g.origin[k] = 0.0; g.n[k] = 1; }
   g.h = 1.0;
@@ -101,12 +102,12 @@ int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g) {
         for (int y = r.lo[1]; y <= r.hi[1]; ++y)
           for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
             const double cc[3] = {lo[0] + (x + 0.5) * h, lo[1] + (y + 0.5) * h, lo[2] + (z + 0.5) * h};
-            if (cube_box_lower_bound(obs[i], &ext[3 * i], cc, hh) <= R)
-              fn((static_cast<uint64_t>(z) * dim[1] + y) * dim[0] + x);
+            const double lb = cube_box_lower_bound(obs[i], &ext[3 * i], cc, hh);
+            if (lb <= R) fn((static_cast<uint64_t>(z) * dim[1] + y) * dim[0] + x, lb);
           }
     };
     std::vector<uint32_t> count(ncell, 0u);
-    for (size_t i = 0; i < n; ++i) for_cells(i, [&](uint64_t c) { ++count[c]; });
+    for (size_t i = 0; i < n; ++i) for_cells(i, [&](uint64_t c, double) { ++count[c]; });
     uint64_t groups = 0;
     for (uint64_t c = 0; c < ncell; ++c) groups += (count[c] + kGridGroup - 1) / kGridGroup;
     if (groups * kGridGroup > kGridMaxItems) continue;
@@ -119,8 +120,30 @@ int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g) {
     g.start[ncell] = at;
     g.items.assign(static_cast<size_t>(at) * kGridGroup, static_cast<uint16_t>(kGridNone));
     std::fill(count.begin(), count.end(), 0u);
+    std::vector<float> lbs;
+    if (by_bound) lbs.assign(g.items.size(), INFINITY);
     for (size_t i = 0; i < n; ++i)  // boxes in ascending id order inside every cell
-      for_cells(i, [&](uint64_t c) { g.items[static_cast<size_t>(g.start[c]) * kGridGroup + count[c]++] = static_cast<uint16_t>(i); });
+      for_cells(i, [&](uint64_t c, double lb) {
+        const size_t at_item = static_cast<size_t>(g.start[c]) * kGridGroup + count[c]++;
+        g.items[at_item] = static_cast<uint16_t>(i);
+        // (the cube test above took the cell with hh exact; the device may file a point within 1e-7 of a face under
+        // the neighbouring cell: the bound gives that much away, and the caller's pad)
+        if (by_bound) lbs[at_item] = static_cast<float>(std::max(0.0, lb * (1.0 - 1e-6) - pad - 1e-6));
+      });
+    if (by_bound) {  // ... then by bound, ascending (ties: by id), the padding last
+      g.glb.assign(at, 0.0f);
+      std::vector<std::pair<float, uint16_t>> cell;
+      for (uint64_t c = 0; c < ncell; ++c) {
+        const size_t b0 = static_cast<size_t>(g.start[c]) * kGridGroup;
+        cell.clear();
+        for (uint32_t e = 0; e < count[c]; ++e) cell.emplace_back(lbs[b0 + e], g.items[b0 + e]);
+        std::sort(cell.begin(), cell.end());
+        for (uint32_t e = 0; e < count[c]; ++e) {
+          g.items[b0 + e] = cell[e].second;
+          if (e % kGridGroup == 0) g.glb[g.start[c] + e / kGridGroup] = std::nextafterf(cell[e].first, -INFINITY) < 0.0f ? 0.0f : std::nextafterf(cell[e].first, -INFINITY);
+        }
+      }
+    }
     for (int k = 0; k < 3; ++k) { g.origin[k] = lo[k]; g.n[k] = dim[k]; }
     g.h = h;
     return MVK_OK;

@@ -99,9 +99,15 @@ struct GridHost {
   int32_t n[3];
   std::vector<uint32_t> start;  // [ncell + 1], in groups of kGridGroup ids
   std::vector<uint16_t> items;  // [start[ncell] * kGridGroup]
+  // by_bound grids: per group, a lower bound of the distance from ANY point of the cell to the group's boxes and to
+  // every box after them in the cell's list (lists sorted by that bound, ascending): a walk that looks for boxes within
+  // some distance of a point stops at the first group whose bound exceeds it.  [start[ncell]]; empty otherwise
+  std::vector<float> glb;
 };
-// every box within `radius` of a point is listed in the cell holding the point
-int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g);
+// every box within `radius` of a point is listed in the cell holding the point.  by_bound: lists sorted by the
+// box-to-cell lower bound instead of by id, with GridHost::glb (the bounds less `pad`, the slack for the device's fp32
+// distances)
+int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_bound = false, double pad = 0.0);
 // far grid: the cell holding a point x lists every box b with l(x, b) <= reach + min over boxes of l(x, .), inside the
 // boxes' bound inflated by `margin` (pad: slack for the device's fp32 centre distances)
 int build_far_grid(const DevObs* obs, size_t n, double reach, double margin, double pad, GridHost& g);
@@ -114,6 +120,7 @@ struct GridDev {
   int32_t pad;
   const uint32_t* start;
   const uint16_t* items;
+  const float* glb;  // per group lower bounds of a by_bound grid (GridHost::glb), or nullptr
 };
 
 struct EvalArgs {

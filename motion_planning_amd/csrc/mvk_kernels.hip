@@ -1744,6 +1744,10 @@ DEV bool grid_collect_nearest(const EvalArgs& A, const GridDev& G, double radius
   int n = 0;
 #pragma unroll 1
   for (unsigned g = gb; g < ge; ++g) {
+    if (G.glb) {  // sorted by the box-to-cell lower bound: this group and every later one lie beyond the threshold
+      const float lb = G.glb[g];
+      if (lb * lb > thr2f) break;
+    }
     const ushort4 v = *reinterpret_cast<const ushort4*>(G.items + static_cast<size_t>(g) * kGridGroup);
     const unsigned short ids[kGridGroup] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1994,6 +1998,14 @@ DEV void dist_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const Sme
   const bool all = wa >> 31, wide = wb >> 31, farg = (wb >> 30) & 1u;
   const unsigned ge = wb & 0x3FFFFFFFu;
   const unsigned g = g0 + sub;
+  // a grid with bounds (GridDev::glb): the walk stops at the first group that lies beyond the item's threshold -- the
+  // lists are sorted by the box-to-cell lower bound, so every later box is beyond it too
+  bool more = active && sub == 0u && g0 + rep < ge;  // the item's owner lane puts the rest of the range back
+  float lb_next = 0.0f;
+  if (more) {
+    const float* __restrict__ glb = all ? nullptr : wide ? A.dgrid2.glb : farg ? nullptr : A.dgrid.glb;
+    if (glb) lb_next = glb[g0 + rep];
+  }
   if (active && g < ge) {
     unsigned ids[kGridGroup];
     if (all) {
@@ -2029,7 +2041,12 @@ DEV void dist_pop(const EvalArgs& A, const DevObsF* __restrict__ obsf, const Sme
                              __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
   }
-  const bool more = active && sub == 0u && g0 + rep < ge;  // the item's owner lane puts the rest of the range back
+  if (more) {
+    const float lim2 = COLLECT ? __uint_as_float(wt)
+                               : __uint_as_float(__hip_atomic_load(reinterpret_cast<lds_uint*>(sm.upper) + slot * kBlock + wave_tid + src, __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_WAVEFRONT));
+    more = lb_next * lb_next <= lim2;
+  }
   head = (head + m) & (kRing - 1);
   qn -= m;
   const unsigned long long bal = __ballot(more);
@@ -4124,6 +4141,9 @@ full_small_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevEx
 #ifndef MVK_AVOID_WAVES
 #define MVK_AVOID_WAVES 2
 #endif
+#ifndef MVK_AVOID_RING   // 1: the cell walks go through the wave's ring (two passes); 0: every lane walks its own (one pass)
+#define MVK_AVOID_RING 0  // (measured, profiles/r03/avoid_flat_drain.txt: the one pass is 2-3 % ahead once the walks stop early)
+#endif
 template <int ROBOT, int NL>
 __global__ void __launch_bounds__(kBlock, MVK_AVOID_WAVES)  // as the full kernel: occupancy over spills
 avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
@@ -4136,9 +4156,25 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   __shared__ unsigned long long sm_ex_res[(kBlock / 64) * kCpBatch];
   __shared__ double sm_ex_s2[(kBlock / 64) * 24 * kCpBatch];
   __shared__ unsigned sm_ex_win[(kBlock / 64) * kCpBatch];
+  // broadphase ring of each wave (dist_push / dist_pop); during a drain the same words hold the owners' nearest points
+  __shared__ __align__(8) unsigned sm_dring[(kBlock / 64) * kDRingWords * kRing];
+  __shared__ unsigned sm_dcnt[kBlock], sm_upper[kBlock], sm_gob[kBlock], sm_rob[kBlock], sm_emin[kBlock];
+  __shared__ unsigned long long sm_mres[kBlock], sm_gmin[kBlock];
+  static_assert(kDRingWords * kRing * 4 >= 6 * 64 * 8, "the ring holds [6][64] doubles");
+  static_assert(24 * kCpBatch >= 64, "the batch buffer holds [64] keys");
   const int wv = threadIdx.x >> 6;
   Smem sm{(lds_double*)sm_cs, (lds_ushort*)sm_list, (lds_double*)sm_ex_item + wv * kCpBatch * kExactItem, (lds_u64*)sm_ex_res + wv * kCpBatch,
           (lds_double*)sm_ex_s2 + wv * 24 * kCpBatch, (lds_uint*)sm_ex_win + wv * kCpBatch};
+  sm.upper = (lds_float*)sm_upper;
+  sm.gcs = nullptr;
+  sm.dring = (lds_uint*)sm_dring + wv * (kDRingWords * kRing);
+  sm.dcnt = (lds_uint*)sm_dcnt + wv * 64;
+  sm.mres = (lds_u64*)sm_mres + wv * 64;
+  sm.gmin = (lds_u64*)sm_gmin + wv * 64;
+  lds_uint* gob = (lds_uint*)sm_gob + wv * 64;        // flat drain: the owner's best box id
+  lds_uint* rob = (lds_uint*)sm_rob + wv * 64;        // ... a round's best box id per owner
+  lds_uint* emin_l = (lds_uint*)sm_emin + wv * 64;    // ... the list index of the owner's smallest separating-axis gap
+  unsigned head = 0, qn = 0;  // the wave's ring (wave-uniform)
   const int tid = threadIdx.x, lane = tid & 63;
   const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + tid;
   const bool in_range = gi < A.n;
@@ -4183,14 +4219,45 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       bool from_grid = false;
       const uint16_t* __restrict__ cell_items = A.dgrid.items;
       if (use_grid) {
+        // The cell of the primitive's centre lists every box within the grid's radius.  Its walk is shared out over
+        // the wave through the ring, as in the full path (dist_push / dist_pop): first the smallest centre distance
+        // of the list -- the primitive's own nearest box sets the threshold here, no bound is known beforehand --
+        // then the boxes within bounding radius + that distance join the lane's candidate list.
+        const bool on = in_range && f32_safe;
+#if MVK_AVOID_RING
+        lds_uint* up = reinterpret_cast<lds_uint*>(sm.upper) + tid;
+        *up = 0x7F800000u;  // +inf
+        const bool inside = grid_cell_in(A.dgrid, pc, on, cell_b, cell_e);
+        dist_push(sm, inside, pc, cell_b, cell_e, 0u, kRangeCell, 0.0f, head, qn);
+#pragma unroll 1
+        while (qn > 0u) dist_pop<false>(A, A.obsf, sm, head, qn);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float best2f = __uint_as_float(*up);
+        const double upd = static_cast<double>(sqrtf(best2f)) * 1.000001 + static_cast<double>(A.f32_delta);
+        // (+inf: nothing listed; beyond the radius the list is not complete for the threshold)
+        const bool answered = inside && best2f < INFINITY && rb + upd + 2.0 * static_cast<double>(A.f32_delta) <= A.dgrid_radius;
+        const float rbf = static_cast<float>(rb) * 1.000001f + 2.0f * A.f32_delta;
+        const float tf = (rbf + sqrtf(best2f) * 1.000001f) * 1.000001f;
+        sm.dcnt[lane] = 0u;
+        dist_push(sm, answered, pc, cell_b, cell_e, 0u, kRangeCell, tf * tf, head, qn);
+#pragma unroll 1
+        while (qn > 0u) dist_pop<true>(A, A.obsf, sm, head, qn);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool scan = in_range && !answered;
+        if (answered) cnt = static_cast<int>(sm.dcnt[lane]);
+#else
+        // (every lane walks its own cell's list, once: the threshold follows the running minimum)
         bool scan = in_range;
-        if (grid_collect_nearest(A, A.dgrid, A.dgrid_radius, sm, in_range && f32_safe, pc, rb, cnt, cell_b, cell_e)) scan = false;
+        if (grid_collect_nearest(A, A.dgrid, A.dgrid_radius, sm, on, pc, rb, cnt, cell_b, cell_e)) scan = false;
+#endif
         if (A.fgrid.start != nullptr && __any(scan && f32_safe)) {  // too far for the grid's radius: the far grid's list
           int c3 = 0;
           unsigned b3 = 0, e3 = 0;
-          const bool inside = grid_cell_in(A.fgrid, pc, scan && f32_safe, b3, e3);
-          far_for_lanes_f32(A, sm, inside, pc, rb, b3, e3, c3);
-          if (inside) {
+          const bool in_far = grid_cell_in(A.fgrid, pc, scan && f32_safe, b3, e3);
+          far_for_lanes_f32(A, sm, in_far, pc, rb, b3, e3, c3);
+          if (in_far) {
             scan = false;
             cnt = c3; cell_b = b3; cell_e = e3;
             cell_items = A.fgrid.items;
@@ -4239,12 +4306,84 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 #endif
       double best = INFINITY, br[3] = {NAN, NAN, NAN}, be[3] = {NAN, NAN, NAN};
       int bi = -1;
+      // Flat drain (no lane's list overflowed, the common case): a primitive's lists have very different lengths --
+      // ten candidates on average, thirty in the longest of 64 -- so instead of every lane scanning its own, the wave
+      // numbers the (lane, candidate) pairs through and takes them 64 at a time: a lane fetches the owner's pose
+      // (cross-lane reads), computes the pair, and the results of a round merge into their owners' records in LDS --
+      // (distance key, box id, nearest points), the minimum of (distance, box id) as the oracle keeps it.
+      const bool flat = use_grid && !__any(in_range && overflow);
+      const int wave_tid = tid - lane;
+      lds_u64* gkey = sm.mres;      // the owner's best distance, as an ordered key
+      lds_u64* rkey = sm.gmin;      // a round's best per owner
+      lds_double* pts = reinterpret_cast<lds_double*>(sm.dring);  // [6][64] world points of the best pair (the ring is idle here)
+      // merge one result per lane (`has`) into its owner's record; several lanes may serve one owner in a round
+      auto merge = [&](bool has, int src, double d, int ob, const double wr[3], const double we[3]) {
+        if (!__any(has)) return;
+        rkey[lane] = ~0ull;
+        rob[lane] = 0xFFFFFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long k = ord_key(d + 0.0);  // (-0 -> +0: one key per value)
+        if (has) __hip_atomic_fetch_min(&rkey[src], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool top = has && rkey[src] == k;
+        if (top) __hip_atomic_fetch_min(&rob[src], static_cast<unsigned>(ob), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (top && rob[src] == static_cast<unsigned>(ob)) {  // the round's winner for this owner: one lane
+          const unsigned long long gk = gkey[src];
+          if (k < gk || (k == gk && static_cast<unsigned>(ob) < gob[src])) {
+            gkey[src] = k;
+            gob[src] = static_cast<unsigned>(ob);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { pts[c * 64 + src] = wr[c]; pts[(3 + c) * 64 + src] = we[c]; }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      };
+      auto to_world = [&](const DevObs& O, const double pr[3], const double pq[3], double wr[3], double we[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {  // box frame -> world (NaN points stay NaN)
+          wr[c] = fma(O.R[3 * c], pr[0], fma(O.R[3 * c + 1], pr[1], fma(O.R[3 * c + 2], pr[2], O.c[c])));
+          we[c] = fma(O.R[3 * c], pq[0], fma(O.R[3 * c + 1], pq[1], fma(O.R[3 * c + 2], pq[2], O.c[c])));
+        }
+      };
+      unsigned T = 0u;
+      if (flat) {
+        unsigned incl = static_cast<unsigned>(todo);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned v = __shfl_up(incl, o);
+          if (lane >= o) incl += v;
+        }
+        T = __shfl(incl, 63);
+        sm.dcnt[lane] = incl;
+        gkey[lane] = ord_key(INFINITY);
+        gob[lane] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pts[c * 64 + lane] = NAN;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      // the owner of pair i of the wave's numbering, and its index in the owner's list
+      auto owner_of = [&](unsigned i, bool act, int& src, unsigned& e) {
+        unsigned lo = 0u, hi = 63u;  // the first lane whose inclusive count exceeds i
+#pragma unroll
+        for (int st_ = 0; st_ < 6; ++st_) {
+          const unsigned mid = (lo + hi) >> 1;
+          if (sm.dcnt[mid] > i) hi = mid; else lo = mid + 1u;
+        }
+        src = act ? static_cast<int>(lo) : lane;
+        e = act ? i - (src > 0 ? sm.dcnt[src - 1] : 0u) : 0u;
+      };
       if (type == MVK_PRIM_BOX) {
         // Every separated primitive needs at least one exact closest-point computation (24 edge-to-box closest
         // pairs, ~30x a separating-axis gap), so the order matters: pass A takes the gap of every candidate
         // (contacts are final there) and finds the smallest; its exact distance comes first and prunes most of the
-        // rest; pass B scans the others with the gap alone, each lane stopping at its next candidate whose gap
-        // still undercuts its minimum, and the wave runs the exact code once per such round.  The oracle keeps
+        // rest; pass B scans the others with the gap alone, and the pairs whose gap still undercuts their owner's
+        // minimum get the exact code, the wave working on a batch of them together.  The oracle keeps
         // the first minimum in ascending box order: out of order, that is the minimum of (distance, box id).
         const double a[3] = {d0, d1, d2};
         auto take = [&](double d, int ob, const DevObs& O, const double pr[3], const double pq[3]) {
@@ -4259,6 +4398,203 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
           }
         };
         const double nan3[3] = {NAN, NAN, NAN};
+        // one (pair, edge): inputs as box_box_exact_cp builds them for its two halves
+        auto edge_item = [&](const double iR[9], const double it_[3], const double ih[3], int ed, double y[3], double z[3]) {
+          const bool second = ed >= 12;
+          double cR[9], cc[3], ca[3], cb[3];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cR[3 * r + c] = second ? iR[3 * c + r] : iR[3 * r + c];
+            const double tb = -fma(iR[r], it_[0], fma(iR[3 + r], it_[1], iR[6 + r] * it_[2]));
+            cc[r] = second ? tb : it_[r];
+            ca[r] = second ? ih[r] : a[r];
+            cb[r] = second ? a[r] : ih[r];
+          }
+          return box_edge_to_box_cp2(second ? ed - 12 : ed, cc, cR, ca, cb, y, z);
+        };
+        // The pairs that need the exact closest points (`need`: relative pose Rr, t; box ob_n), computed by the whole
+        // wave, kCpBatch at a time: (pair, edge) items over all lanes, an LDS atomic min per pair over its 24 squared
+        // distances, a second one over the edge indices that reach it (the lowest wins, as in the one-lane form: robot
+        // edges before box edges, ascending), and the lane that holds the pair repeats that one edge for its points.
+        // Same arithmetic per edge, so the result keeps its bits.  `deliver` hands (distance, box, points) over.
+        auto run_cp = [&](bool need, int ob_n, const double Rr[9], const double t[3], auto&& deliver) {
+          unsigned long long pend = __ballot(need);
+#pragma unroll 1
+          while (pend) {
+            const int rank = __popcll(pend & ((1ull << lane) - 1ull));
+            const bool mine = need && ((pend >> lane) & 1ull) && rank < kCpBatch;
+            const int E = min(static_cast<int>(__popcll(pend)), kCpBatch);
+            double h[3] = {0.0, 0.0, 0.0};
+            if (mine) {
+              const DevObs& O = obs[ob_n];
+              h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
+#pragma unroll
+              for (int c = 0; c < 9; ++c) sm.ex_item[rank * kExactItem + c] = Rr[c];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { sm.ex_item[rank * kExactItem + 9 + c] = t[c]; sm.ex_item[rank * kExactItem + 12 + c] = h[c]; }
+              sm.ex_res[rank] = 0x7FF0000000000000ull;  // +inf
+              sm.ex_win[rank] = 0xFFFFFFFFu;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (int it = lane; it < 24 * E; it += 64) {
+              const int pr_ = it / 24, ed = it - 24 * pr_;
+              double iR[9], it_[3], ih[3], y[3], z[3];
+#pragma unroll
+              for (int c = 0; c < 9; ++c) iR[c] = sm.ex_item[pr_ * kExactItem + c];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { it_[c] = sm.ex_item[pr_ * kExactItem + 9 + c]; ih[c] = sm.ex_item[pr_ * kExactItem + 12 + c]; }
+              const double s2 = edge_item(iR, it_, ih, ed, y, z);
+              sm.ex_s2[it] = s2;
+              __hip_atomic_fetch_min(&sm.ex_res[pr_], static_cast<unsigned long long>(__double_as_longlong(s2)), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (int it = lane; it < 24 * E; it += 64) {
+              const int pr_ = it / 24, ed = it - 24 * pr_;
+              if (static_cast<unsigned long long>(__double_as_longlong(sm.ex_s2[it])) == sm.ex_res[pr_])
+                __hip_atomic_fetch_min(&sm.ex_win[pr_], static_cast<unsigned>(ed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double dd_ = INFINITY, pr[3] = {NAN, NAN, NAN}, pq[3] = {NAN, NAN, NAN};
+            if (mine) {
+              const int ed = static_cast<int>(sm.ex_win[rank]);
+              double y[3], z[3];
+              const double s2 = edge_item(Rr, t, h, ed, y, z);
+              if (ed < 12) {  // y on the robot's edge, z on the box (box frame)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { pr[c] = y[c]; pq[c] = z[c]; }
+              } else {        // y on the box's edge, z on the robot (primitive frame): x_B = Rr x_A + t
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                  pq[c] = fma(Rr[3 * c], y[0], fma(Rr[3 * c + 1], y[1], fma(Rr[3 * c + 2], y[2], t[c])));
+                  pr[c] = fma(Rr[3 * c], z[0], fma(Rr[3 * c + 1], z[1], fma(Rr[3 * c + 2], z[2], t[c])));
+                }
+              }
+              dd_ = sqrt(s2);
+            }
+            deliver(mine, dd_, pr, pq);
+            pend &= ~__ballot(mine);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        };
+        if (flat) {
+          lds_u64* amin = reinterpret_cast<lds_u64*>(sm.ex_s2);  // [64] the smallest positive gap per owner (pass A; the batch buffer is idle)
+          amin[lane] = ord_key(INFINITY);
+          emin_l[lane] = 0xFFFFFFFFu;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          PROF_T0(t_a);
+#pragma unroll 1
+          for (unsigned base = 0; base < T; base += 64u) {  // pass A
+            const unsigned i = base + static_cast<unsigned>(lane);
+            const bool act = i < T;
+            int src; unsigned e;
+            owner_of(i, act, src, e);
+            double spc[3], sPR[9];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) spc[c] = __shfl(pc[c], src);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sPR[c] = __shfl(PR[c], src);
+            bool contact = false, pos = false;
+            double g = INFINITY;
+            int ob = 0;
+            if (act) {
+              ob = sm.list[e * kBlock + wave_tid + src];
+              const DevObs& O = obs[ob];
+              double Rr[9], t[3];
+              to_box_frame(O, spc, t);
+              box_rel(O, sPR, Rr);
+              const double cut = ord_val(amin[src]);
+              g = box_box_sat<true>(t, Rr, a, O.h, cut);
+              contact = g <= 0.0;
+              pos = !contact && g < cut;
+              if (pos) __hip_atomic_fetch_min(&amin[src], ord_key(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (pos && amin[src] == ord_key(g)) emin_l[src] = e;  // (equal gaps: either pair may go first)
+            merge(contact, src, g, ob, nan3, nan3);               // in contact: no points
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          PROF_CLK(3, t_a);
+          PROF_T0(t_f);
+          const unsigned emin = emin_l[lane];
+          {
+            const bool first = emin != 0xFFFFFFFFu && ord_val(amin[lane]) <= ord_val(gkey[lane]) + kSatSlack;
+            if (__any(first)) {
+              if (first) {  // every lane its own pair: the wave is full here
+                const int ob = sm.list[emin * kBlock + tid];
+                const DevObs O = obs[ob];
+                double Rr[9], t[3], pr[3], pq[3], wr[3], we[3];
+                to_box_frame(O, pc, t);
+                box_rel(O, PR, Rr);
+                const double d = box_box_exact_cp(t, Rr, a, O.h, pr, pq);
+                to_world(O, pr, pq, wr, we);
+                const unsigned long long k = ord_key(d + 0.0), gk = gkey[lane];
+                if (k < gk || (k == gk && static_cast<unsigned>(ob) < gob[lane])) {
+                  gkey[lane] = k;
+                  gob[lane] = static_cast<unsigned>(ob);
+#pragma unroll
+                  for (int c = 0; c < 3; ++c) { pts[c * 64 + lane] = wr[c]; pts[(3 + c) * 64 + lane] = we[c]; }
+                }
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          PROF_CLK(4, t_f);
+#pragma unroll 1
+          for (unsigned base = 0; base < T; base += 64u) {  // pass B
+            const unsigned i = base + static_cast<unsigned>(lane);
+            const bool act = i < T;
+            int src; unsigned e;
+            owner_of(i, act, src, e);
+            double spc[3], sPR[9];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) spc[c] = __shfl(pc[c], src);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sPR[c] = __shfl(PR[c], src);
+            bool need = false;
+            double g = INFINITY, Rr[9], t[3];
+            int ob = 0;
+            rkey[lane] = ~0ull;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (act && e != emin_l[src]) {
+              ob = sm.list[e * kBlock + wave_tid + src];
+              const DevObs& O = obs[ob];
+              to_box_frame(O, spc, t);
+              box_rel(O, sPR, Rr);
+              const double cut = ord_val(gkey[src]) + kSatSlack;  // (kSatSlack: the minimum does not depend on the order of the pairs)
+              g = box_box_sat<true>(t, Rr, a, O.h, cut);
+              need = g > 0.0 && g <= cut;
+              if (need) __hip_atomic_fetch_min(&rkey[src], ord_key(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (__any(need)) {
+              auto deliver = [&](bool mine, double d, const double pr[3], const double pq[3]) {
+                double wr[3] = {NAN, NAN, NAN}, we[3] = {NAN, NAN, NAN};
+                if (mine) to_world(obs[ob], pr, pq, wr, we);
+                merge(mine, src, d, ob, wr, we);
+              };
+              // per owner the pair with the smallest gap first; the others are re-tested against the result
+              const bool first = need && rkey[src] == ord_key(g);
+              __builtin_amdgcn_wave_barrier();
+              run_cp(first, ob, Rr, t, deliver);
+              const bool again = need && !first && g <= ord_val(gkey[src]) + kSatSlack;
+              run_cp(again, ob, Rr, t, deliver);
+            }
+          }
+        } else {
         double gmin = INFINITY;
         int emin = -1;
         PROF_T0(t_a);
@@ -4313,88 +4649,35 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
             }
             ++e;
           }
-          // the pairs that still need the exact closest points -- a few per wave, unlike the first round -- are
-          // computed by the whole wave, kCpBatch at a time: (pair, edge) items over all lanes, an LDS atomic min
-          // per pair over its 24 squared distances, a second one over the edge indices that reach it (the lowest
-          // wins, as in the one-lane form: robot edges before box edges, ascending), and the owner lane repeats
-          // that one edge for its points.  Same arithmetic per edge, so the result keeps its bits.
-          unsigned long long pend = __ballot(need);
+          run_cp(need, ob_n, Rr, t, [&](bool mine, double d, const double pr[3], const double pq[3]) {
+            if (mine) take(d, ob_n, obs[ob_n], pr, pq);
+          });
+        }
+        }
+      } else if (flat) {
+        // closed-form primitives: one round per 64 pairs, distance and nearest points at once
 #pragma unroll 1
-          while (pend) {
-            const int rank = __popcll(pend & ((1ull << lane) - 1ull));
-            const bool mine = need && ((pend >> lane) & 1ull) && rank < kCpBatch;
-            const int E = min(static_cast<int>(__popcll(pend)), kCpBatch);
-            double h[3] = {0.0, 0.0, 0.0};
-            if (mine) {
-              const DevObs& O = obs[ob_n];
-              h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
+        for (unsigned base = 0; base < T; base += 64u) {
+          const unsigned i = base + static_cast<unsigned>(lane);
+          const bool act = i < T;
+          int src; unsigned e;
+          owner_of(i, act, src, e);
+          double spc[3], sPR[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-              for (int c = 0; c < 9; ++c) sm.ex_item[rank * kExactItem + c] = Rr[c];
+          for (int c = 0; c < 3; ++c) spc[c] = __shfl(pc[c], src);
 #pragma unroll
-              for (int c = 0; c < 3; ++c) { sm.ex_item[rank * kExactItem + 9 + c] = t[c]; sm.ex_item[rank * kExactItem + 12 + c] = h[c]; }
-              sm.ex_res[rank] = 0x7FF0000000000000ull;  // +inf
-              sm.ex_win[rank] = 0xFFFFFFFFu;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // one (pair, edge): inputs as box_box_exact_cp builds them for its two halves
-            auto edge_item = [&](const double iR[9], const double it_[3], const double ih[3], int ed, double y[3], double z[3]) {
-              const bool second = ed >= 12;
-              double cR[9], cc[3], ca[3], cb[3];
-#pragma unroll
-              for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) cR[3 * r + c] = second ? iR[3 * c + r] : iR[3 * r + c];
-                const double tb = -fma(iR[r], it_[0], fma(iR[3 + r], it_[1], iR[6 + r] * it_[2]));
-                cc[r] = second ? tb : it_[r];
-                ca[r] = second ? ih[r] : a[r];
-                cb[r] = second ? a[r] : ih[r];
-              }
-              return box_edge_to_box_cp2(second ? ed - 12 : ed, cc, cR, ca, cb, y, z);
-            };
-#pragma unroll 1
-            for (int it = lane; it < 24 * E; it += 64) {
-              const int pr_ = it / 24, ed = it - 24 * pr_;
-              double iR[9], it_[3], ih[3], y[3], z[3];
-#pragma unroll
-              for (int c = 0; c < 9; ++c) iR[c] = sm.ex_item[pr_ * kExactItem + c];
-#pragma unroll
-              for (int c = 0; c < 3; ++c) { it_[c] = sm.ex_item[pr_ * kExactItem + 9 + c]; ih[c] = sm.ex_item[pr_ * kExactItem + 12 + c]; }
-              const double s2 = edge_item(iR, it_, ih, ed, y, z);
-              sm.ex_s2[it] = s2;
-              __hip_atomic_fetch_min(&sm.ex_res[pr_], static_cast<unsigned long long>(__double_as_longlong(s2)), __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-            for (int it = lane; it < 24 * E; it += 64) {
-              const int pr_ = it / 24, ed = it - 24 * pr_;
-              if (static_cast<unsigned long long>(__double_as_longlong(sm.ex_s2[it])) == sm.ex_res[pr_])
-                __hip_atomic_fetch_min(&sm.ex_win[pr_], static_cast<unsigned>(ed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (mine) {
-              const int ed = static_cast<int>(sm.ex_win[rank]);
-              double y[3], z[3], pr[3], pq[3];
-              const double s2 = edge_item(Rr, t, h, ed, y, z);
-              if (ed < 12) {  // y on the robot's edge, z on the box (box frame)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { pr[c] = y[c]; pq[c] = z[c]; }
-              } else {        // y on the box's edge, z on the robot (primitive frame): x_B = Rr x_A + t
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                  pq[c] = fma(Rr[3 * c], y[0], fma(Rr[3 * c + 1], y[1], fma(Rr[3 * c + 2], y[2], t[c])));
-                  pr[c] = fma(Rr[3 * c], z[0], fma(Rr[3 * c + 1], z[1], fma(Rr[3 * c + 2], z[2], t[c])));
-                }
-              }
-              take(sqrt(s2), ob_n, obs[ob_n], pr, pq);
-            }
-            pend &= ~__ballot(mine);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+          for (int c = 0; c < 3; ++c) sPR[3 * c + 2] = __shfl(PR[3 * c + 2], src);  // (a capsule's axis: all narrow_cp() reads)
+          double d = INFINITY, wr[3] = {NAN, NAN, NAN}, we[3] = {NAN, NAN, NAN};
+          int ob = 0;
+          if (act) {
+            ob = sm.list[e * kBlock + wave_tid + src];
+            const DevObs O = obs[ob];
+            double t[3], pr[3], pq[3];
+            to_box_frame(O, spc, t);
+            d = narrow_cp(type, sPR, d0, d1, d2, O, t, pr, pq, INFINITY);
+            to_world(O, pr, pq, wr, we);
           }
+          merge(act, src, d, ob, wr, we);
         }
       } else {
 #pragma unroll 1
@@ -4416,6 +4699,19 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
             }
           }
         }
+      }
+      if (flat) {  // the owner's record
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned go = gob[lane];
+        if (go != 0xFFFFFFFFu) {
+          best = ord_val(gkey[lane]);
+          bi = static_cast<int>(go);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { br[c] = pts[c * 64 + lane]; be[c] = pts[(3 + c) * 64 + lane]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
       PROF_CLK(1, t_d);
       PROF_T0(t_r);
