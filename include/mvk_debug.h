@@ -21,6 +21,14 @@ int mvk_debug_f32_bounds(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld,
  * tests/test_gpu_fused_giveup.py.  reset != 0 clears the count after reading it. */
 long long mvk_debug_fused_giveups(mvk_ctx* ctx, int reset);
 
+/* The distance grids' form of mvk_broadphase_query (mvk_grid.cpp build_grid, by_bound): per point the ids of its
+ * cell's list in list order -- sorted by the box-to-cell lower bound -- and, per entry, the bound of its group of four
+ * (less `pad`): a lower bound of the distance from any point of the cell to that entry and to every later one, which
+ * is what lets the kernels' walks stop early.  counts[i] = entries of point i (may exceed cap; ids/bounds hold the
+ * first cap).  Host only.  tests/test_grid_bounds.py. */
+int mvk_debug_grid_bounds(const mvk_box* boxes, size_t n_boxes, double radius, double pad, const double* points,
+                          size_t n_points, int32_t* counts, int32_t* ids, float* bounds, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -205,6 +205,7 @@ COMM_ID_BYTES = 128
 DEBUG_PROTOTYPES = {
     "mvk_debug_f32_bounds": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, vp]),
     "mvk_debug_fused_giveups": (C.c_longlong, [vp, ip]),
+    "mvk_debug_grid_bounds": (ip, [PB, sz, d, d, vp, sz, vp, vp, vp, ip]),
 }
 
 

@@ -371,6 +371,13 @@ void derive_extras(const mvk_model* m, DevExtras* x) {
         if (r < best) { best = r; x->grp_lead[g] = li; }
       }
       x->grp_rb[g] = x->grp_begin[g + 1] - x->grp_begin[g] == 1 ? best : best * (1.0 + 1e-12) + 1e-12;
+      // avoidance rows: no bound is shared between primitives there.  With L the leader centre's distance to its nearest
+      // box, a member at offset o from the leader is at most L + o from that box, and a box at centre distance l from
+      // the leader is at least l - o - (member's radius) from the member: the member's nearest box has l <= L + 2 o + radius
+      double rq = 0.0;
+      for (int oi = x->grp_begin[g]; oi < x->grp_begin[g + 1]; ++oi)
+        rq = std::fmax(rq, x->prim_bound[x->prim_order[oi]] + 2.0 * apart(x->prim_order[oi], x->prim_order[x->grp_lead[g]]));
+      x->grp_rq[g] = x->grp_begin[g + 1] - x->grp_begin[g] == 1 ? rq : rq * (1.0 + 1e-12) + 1e-12;
     }
     for (int k = m->n_seg; k <= MVK_MAX_SEG; ++k) x->seg_grp_begin[k] = ng;
     for (int g = ng; g <= MVK_MAX_PRIM; ++g) x->grp_begin[g] = x->seg_prim_begin[m->n_seg];
@@ -459,7 +466,13 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
     bool built = false;
     // lists sorted by the box-to-cell lower bound, so that a walk stops early (diagnostics: MVK_NO_GRID_BOUNDS=1)
     const bool by_bound = !(std::getenv("MVK_NO_GRID_BOUNDS") && std::getenv("MVK_NO_GRID_BOUNDS")[0] == '1');
-    for (int attempt = 0; attempt < 3 && !built; ++attempt, slack *= 0.5) built = build_grid(host.data(), n, rb + slack, gh, by_bound, 4.0 * static_cast<double>(c->f32_delta)) == MVK_OK;
+    // the second grid's cells: with bounds, finer cells end the walks sooner (a box's bound is taken against the whole
+    // cell); the first grid's cells are as fine as the cell budget allows already
+    double cell_frac = (by_bound && g == 1) ? 0.25 : 0.5;
+    if (const char* ov = std::getenv("MVK_GRID_CELL_FRAC")) if (g == 1 && std::atof(ov) >= 0.05 && std::atof(ov) <= 1.0) cell_frac = std::atof(ov);  // diagnostics
+    double rbg = rb;  // (the avoidance rows' walks ask with grp_rq)
+    if (g == 1) for (int gi = 0; gi < c->extras.n_grp; ++gi) rbg = std::fmax(rbg, c->extras.grp_rq[gi]);
+    for (int attempt = 0; attempt < 3 && !built; ++attempt, slack *= 0.5) built = build_grid(host.data(), n, rbg + slack, gh, by_bound, 4.0 * static_cast<double>(c->f32_delta), cell_frac) == MVK_OK;
     if (!built) continue;  // too dense for the grid's budget: the sweep stays
     double mean_len = 0.0;
     for (int i = 0; i < kProbe; ++i) {
@@ -898,6 +911,32 @@ extern "C" int mvk_broadphase_query(const mvk_box* boxes, size_t n_boxes, double
     for (int e = 0; e < padded; ++e)
       if (list[e] != kGridNone) {
         if (k < cap) ids[i * static_cast<size_t>(cap) + k] = list[e];
+        ++k;
+      }
+    counts[i] = k;
+  }
+  return MVK_OK;
+}
+
+extern "C" int mvk_debug_grid_bounds(const mvk_box* boxes, size_t n_boxes, double radius, double pad, const double* points,
+                                     size_t n_points, int32_t* counts, int32_t* ids, float* bounds, int cap) {
+  if (!(radius >= 0.0) || !(pad >= 0.0) || (n_points && (!points || !counts)) || cap < 0 || (cap > 0 && (!ids || !bounds)))
+    return fail(MVK_ERR_INVALID_ARG, "mvk_debug_grid_bounds: bad argument");
+  std::vector<DevObs> host;
+  if (int rc = boxes_to_obs(boxes, n_boxes, host)) return rc;
+  GridHost g;
+  if (int rc = build_grid(host.data(), n_boxes, radius, g, true, pad)) return rc;
+  for (size_t i = 0; i < n_points; ++i) {
+    const uint16_t* list = nullptr;
+    const int padded = grid_query(g, points + 3 * i, &list);
+    const size_t group0 = padded ? static_cast<size_t>(list - g.items.data()) / kGridGroup : 0;
+    int k = 0;
+    for (int e = 0; e < padded; ++e)
+      if (list[e] != kGridNone) {
+        if (k < cap) {
+          ids[i * static_cast<size_t>(cap) + k] = list[e];
+          bounds[i * static_cast<size_t>(cap) + k] = g.glb[group0 + e / kGridGroup];
+        }
         ++k;
       }
     counts[i] = k;

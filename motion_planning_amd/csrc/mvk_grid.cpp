@@ -52,7 +52,7 @@ double cube_box_lower_bound(const DevObs& o, const double ext[3], const double c
 
 }  // namespace
 
-int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_bound, double pad) {
+int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_bound, double pad, double cell_frac) {
   g.start.clear();
   g.items.clear();
   g.glb.clear();
@@ -77,7 +77,7 @@ int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_
       hi[k] = std::max(hi[k], obs[i].c[k] + e + R);
     }
   const double vol = (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]);
-  double h = std::max(0.5 * R, std::cbrt(vol / static_cast<double>(kGridMaxCells)));
+  double h = std::max(cell_frac * R, std::cbrt(vol / static_cast<double>(kGridMaxCells)));
   for (int attempt = 0; attempt < 40; ++attempt, h *= 1.25) {
     uint64_t ncell = 1;
     int dim[3];

@@ -76,6 +76,7 @@ struct DevExtras {
   int32_t grp_lead[MVK_MAX_PRIM];  // index into prim_order of the member the broadphase is centred on
   int32_t seg_grp_begin[MVK_MAX_SEG + 1];
   double grp_rb[MVK_MAX_PRIM];
+  double grp_rq[MVK_MAX_PRIM];   // avoidance rows: the cell walk's radius term -- max over members of (bounding radius + twice the distance to the leader's centre)
   double grp_rb_max;  // >= every prim_bound: the radius the distance grids and the far grid are built for
   int32_t prim_order[MVK_MAX_PRIM];
   double seg_sph[MVK_MAX_SEG][4];  // per segment: sphere (centre in the segment frame, radius) holding its primitives
@@ -106,8 +107,8 @@ struct GridHost {
 };
 // every box within `radius` of a point is listed in the cell holding the point.  by_bound: lists sorted by the
 // box-to-cell lower bound instead of by id, with GridHost::glb (the bounds less `pad`, the slack for the device's fp32
-// distances)
-int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_bound = false, double pad = 0.0);
+// distances).  cell_frac: cell side as a fraction of the radius, where the cell budget allows
+int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_bound = false, double pad = 0.0, double cell_frac = 0.5);
 // far grid: the cell holding a point x lists every box b with l(x, b) <= reach + min over boxes of l(x, .), inside the
 // boxes' bound inflated by `margin` (pad: slack for the device's fp32 centre distances)
 int build_far_grid(const DevObs* obs, size_t n, double reach, double margin, double pad, GridHost& g);

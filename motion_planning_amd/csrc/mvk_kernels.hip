@@ -1734,14 +1734,14 @@ DEV bool exact_pair(const mvk_model* __restrict__ M, const DevExtras* __restrict
 // beforehand there: the primitive's own nearest box sets it).  The threshold follows the running minimum, so the
 // list also keeps a few boxes met before the nearest one -- the drain's separating-axis gaps discard them.
 DEV bool grid_collect_nearest(const EvalArgs& A, const GridDev& G, double radius, const Smem& sm, bool on, const double pc[3], double rb,
-                              int& cnt, unsigned& gb, unsigned& ge) {
+                              int& cnt, unsigned& gb, unsigned& ge, int* e_near = nullptr) {
   const int tid = threadIdx.x;
   const DevObsF* __restrict__ obsf = A.obsf;
   const bool inside = grid_cell_in(G, pc, on, gb, ge);
   const float x = static_cast<float>(pc[0]), y = static_cast<float>(pc[1]), z = static_cast<float>(pc[2]);
   const float rbf = static_cast<float>(rb) * 1.000001f + 2.0f * A.f32_delta;
   float best2f = INFINITY, thr2f = INFINITY;
-  int n = 0;
+  int n = 0, n_best = 0;
 #pragma unroll 1
   for (unsigned g = gb; g < ge; ++g) {
     if (G.glb) {  // sorted by the box-to-cell lower bound: this group and every later one lie beyond the threshold
@@ -1756,6 +1756,7 @@ DEV bool grid_collect_nearest(const EvalArgs& A, const GridDev& G, double radius
       if (ids[e] != kGridNone) {
         if (l2 < best2f) {
           best2f = l2;
+          n_best = n;  // (it joins the list below: l2 <= its own threshold)
           const float t = (rbf + sqrtf(l2) * 1.000001f) * 1.000001f;
           thr2f = t * t;
         }
@@ -1769,6 +1770,7 @@ DEV bool grid_collect_nearest(const EvalArgs& A, const GridDev& G, double radius
   const double up = static_cast<double>(sqrtf(best2f)) * 1.000001 + static_cast<double>(A.f32_delta);
   if (!(inside && best2f < INFINITY && rb + up + 2.0 * static_cast<double>(A.f32_delta) <= radius)) return false;  // (+inf: nothing listed)
   cnt = n;
+  if (e_near) *e_near = n_best;
   return true;
 }
 
@@ -4173,7 +4175,18 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   sm.gmin = (lds_u64*)sm_gmin + wv * 64;
   lds_uint* gob = (lds_uint*)sm_gob + wv * 64;        // flat drain: the owner's best box id
   lds_uint* rob = (lds_uint*)sm_rob + wv * 64;        // ... a round's best box id per owner
-  lds_uint* emin_l = (lds_uint*)sm_emin + wv * 64;    // ... the list index of the owner's smallest separating-axis gap
+  lds_uint* kmask = (lds_uint*)sm_emin + wv * 64;     // ... the list entries an owner keeps after the centre bound, one bit each
+  static_assert(kListCap <= 32, "one mask bit per list entry");
+  // the list index of the j-th kept entry
+  auto nth_kept = [](unsigned m, unsigned j) {
+    unsigned pos = 0u;
+#pragma unroll
+    for (unsigned w = 16u; w >= 1u; w >>= 1) {
+      const unsigned c = static_cast<unsigned>(__popc((m >> pos) & ((1u << w) - 1u)));
+      if (j >= c) { pos += w; j -= c; }
+    }
+    return pos;
+  };
   unsigned head = 0, qn = 0;  // the wave's ring (wave-uniform)
   const int tid = threadIdx.x, lane = tid & 63;
   const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + tid;
@@ -4200,21 +4213,24 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
   bool ok = true;
   PROF_ACC_DECL;
   const bool use_grid = A.dgrid.start != nullptr;
+  const bool grouped = use_grid && X->n_grp > 0;  // (the sweep over all boxes of small scenes keeps one primitive at a time)
   const bool f32_safe = fmax(fabs(st[0]), fmax(fabs(st[1]), fabs(st[2]))) + X->reach <= A.f32_range;
 #pragma unroll 1
   for (int k = 0; k < S::kSeg; ++k) {
     if (k > 0) advance_frame(M, sm, tid, k, R, p);
-    const int pb = X->seg_prim_begin[k], pe = X->seg_prim_begin[k + 1];
+    const int gfirst = grouped ? X->seg_grp_begin[k] : X->seg_prim_begin[k], glast = grouped ? X->seg_grp_begin[k + 1] : X->seg_prim_begin[k + 1];
 #pragma unroll 1
-    for (int qi = pb; qi < pe; ++qi) {
-      const int q = X->prim_order[qi];
-      const int type = M->prim_type[q];
-      double pc[3], PR[9];
-      prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
-      const double rb = X->prim_bound[q];
-      const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+    for (int g = gfirst; g < glast; ++g) {
+      // One cell walk per GROUP of co-located primitives (DevExtras::grp_begin, as in the full path): about the
+      // leader's centre, with the radius that keeps the list complete for every member (grp_rq); every member then
+      // drains that one list -- its own bound removes what the wider radius let in.
+      const int qb = grouped ? X->grp_begin[g] : g, qe = grouped ? X->grp_begin[g + 1] : g + 1;
+      double pcl[3];
+      prim_pose<S::kGimbal, false>(M, X->prim_order[grouped ? X->grp_lead[g] : g], R, p, pcl, nullptr);
+      const double rq = grouped ? X->grp_rq[g] : X->prim_bound[X->prim_order[qb]];
       PROF_T0(t_c);
       int cnt = 0;
+      int e_near = 0;  // the list index of the candidate nearest by centre distance, where the broadphase knows it
       unsigned cell_b = 0, cell_e = 0;
       bool from_grid = false;
       const uint16_t* __restrict__ cell_items = A.dgrid.items;
@@ -4227,8 +4243,8 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 #if MVK_AVOID_RING
         lds_uint* up = reinterpret_cast<lds_uint*>(sm.upper) + tid;
         *up = 0x7F800000u;  // +inf
-        const bool inside = grid_cell_in(A.dgrid, pc, on, cell_b, cell_e);
-        dist_push(sm, inside, pc, cell_b, cell_e, 0u, kRangeCell, 0.0f, head, qn);
+        const bool inside = grid_cell_in(A.dgrid, pcl, on, cell_b, cell_e);
+        dist_push(sm, inside, pcl, cell_b, cell_e, 0u, kRangeCell, 0.0f, head, qn);
 #pragma unroll 1
         while (qn > 0u) dist_pop<false>(A, A.obsf, sm, head, qn);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -4236,11 +4252,11 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
         const float best2f = __uint_as_float(*up);
         const double upd = static_cast<double>(sqrtf(best2f)) * 1.000001 + static_cast<double>(A.f32_delta);
         // (+inf: nothing listed; beyond the radius the list is not complete for the threshold)
-        const bool answered = inside && best2f < INFINITY && rb + upd + 2.0 * static_cast<double>(A.f32_delta) <= A.dgrid_radius;
-        const float rbf = static_cast<float>(rb) * 1.000001f + 2.0f * A.f32_delta;
+        const bool answered = inside && best2f < INFINITY && rq + upd + 2.0 * static_cast<double>(A.f32_delta) <= A.dgrid_radius;
+        const float rbf = static_cast<float>(rq) * 1.000001f + 2.0f * A.f32_delta;
         const float tf = (rbf + sqrtf(best2f) * 1.000001f) * 1.000001f;
         sm.dcnt[lane] = 0u;
-        dist_push(sm, answered, pc, cell_b, cell_e, 0u, kRangeCell, tf * tf, head, qn);
+        dist_push(sm, answered, pcl, cell_b, cell_e, 0u, kRangeCell, tf * tf, head, qn);
 #pragma unroll 1
         while (qn > 0u) dist_pop<true>(A, A.obsf, sm, head, qn);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -4250,25 +4266,27 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 #else
         // (every lane walks its own cell's list, once: the threshold follows the running minimum)
         bool scan = in_range;
-        if (grid_collect_nearest(A, A.dgrid, A.dgrid_radius, sm, on, pc, rb, cnt, cell_b, cell_e)) scan = false;
+        if (grid_collect_nearest(A, A.dgrid, A.dgrid_radius, sm, on, pcl, rq, cnt, cell_b, cell_e, &e_near)) scan = false;
 #endif
         if (A.fgrid.start != nullptr && __any(scan && f32_safe)) {  // too far for the grid's radius: the far grid's list
           int c3 = 0;
           unsigned b3 = 0, e3 = 0;
-          const bool in_far = grid_cell_in(A.fgrid, pc, scan && f32_safe, b3, e3);
-          far_for_lanes_f32(A, sm, in_far, pc, rb, b3, e3, c3);
+          const bool in_far = grid_cell_in(A.fgrid, pcl, scan && f32_safe, b3, e3);
+          far_for_lanes_f32(A, sm, in_far, pcl, rq, b3, e3, c3);
           if (in_far) {
             scan = false;
             cnt = c3; cell_b = b3; cell_e = e3;
             cell_items = A.fgrid.items;
+            e_near = 0;
           }
         }
         from_grid = !scan;
         double b2 = INFINITY;
         int c2 = 0;
-        sweep_for_lanes_f32(A, sm, scan && f32_safe, pc, rb, INFINITY, cnt);
+        if (scan) e_near = 0;
+        sweep_for_lanes_f32(A, sm, scan && f32_safe, pcl, rq, INFINITY, cnt);
         const bool slow = scan && !f32_safe;
-        sweep_for_lanes(A, obs, sm, slow, pc, rb, INFINITY, b2, c2);
+        sweep_for_lanes(A, obs, sm, slow, pcl, rq, INFINITY, b2, c2);
 #ifdef MVK_PROF_COUNTS
         PROF_LANES(37, scan);
 #endif
@@ -4276,14 +4294,14 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
       } else {
         auto centre_dist2 = [&](const DevObs& O) {
           double t[3];
-          to_box_frame(O, pc, t);
+          to_box_frame(O, pcl, t);
           return point_box_dist2(t, O.h);
         };
         // the primitive's origin lies inside it: the nearest box to the origin bounds the separation from above
         double best2 = INFINITY;
 #pragma unroll 2
         for (int ob = 0; ob < A.n_obs; ++ob) best2 = fmin(best2, centre_dist2(obs[ob]));
-        const double thr = rb + sqrt(best2);
+        const double thr = rq + sqrt(best2);
         const double thr2 = thr * thr * (1.0 + 1e-12);
 #pragma unroll 2
         for (int ob = 0; ob < A.n_obs; ++ob) {
@@ -4300,10 +4318,18 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
         return !overflow ? sm.list[e * kBlock + tid] : (from_cell ? cell_items[static_cast<size_t>(cell_b) * kGridGroup + e] : e);
       };
       PROF_CLK(0, t_c);
-      PROF_T0(t_d);
 #ifdef MVK_PROF_COUNTS
       PROF_LANES(36, in_range); PROF_LANES(38, in_range && overflow); PROF_SUM(39, in_range ? cnt : 0);
 #endif
+#pragma unroll 1
+      for (int qm = qb; qm < qe; ++qm) {
+      const int q = X->prim_order[qm];
+      const int type = M->prim_type[q];
+      double pc[3], PR[9];
+      prim_pose<S::kGimbal, true>(M, q, R, p, pc, PR);
+      const double rb = X->prim_bound[q];
+      const double d0 = M->prim_dim[q][0], d1 = M->prim_dim[q][1], d2 = M->prim_dim[q][2];
+      PROF_T0(t_d);
       double best = INFINITY, br[3] = {NAN, NAN, NAN}, be[3] = {NAN, NAN, NAN};
       int bi = -1;
       // Flat drain (no lane's list overflowed, the common case): a primitive's lists have very different lengths --
@@ -4351,22 +4377,6 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
         }
       };
       unsigned T = 0u;
-      if (flat) {
-        unsigned incl = static_cast<unsigned>(todo);
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const unsigned v = __shfl_up(incl, o);
-          if (lane >= o) incl += v;
-        }
-        T = __shfl(incl, 63);
-        sm.dcnt[lane] = incl;
-        gkey[lane] = ord_key(INFINITY);
-        gob[lane] = 0xFFFFFFFFu;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) pts[c * 64 + lane] = NAN;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
       // the owner of pair i of the wave's numbering, and its index in the owner's list
       auto owner_of = [&](unsigned i, bool act, int& src, unsigned& e) {
         unsigned lo = 0u, hi = 63u;  // the first lane whose inclusive count exceeds i
@@ -4378,6 +4388,87 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
         src = act ? static_cast<int>(lo) : lane;
         e = act ? i - (src > 0 ? sm.dcnt[src - 1] : 0u) : 0u;
       };
+      auto number_pairs = [&](unsigned mine) {  // inclusive counts into dcnt, the wave's total into T
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned v = __shfl_up(incl, o);
+          if (lane >= o) incl += v;
+        }
+        T = __shfl(incl, 63);
+        sm.dcnt[lane] = incl;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      };
+      if (flat) {
+        gkey[lane] = ord_key(INFINITY);
+        gob[lane] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pts[c * 64 + lane] = NAN;
+        // Round 0: every lane its own candidate nearest by centre distance (the broadphase knows it), in full -- for a
+        // box the separating-axis gap and, when separated, the exact closest points.  Its distance is close to the
+        // primitive's minimum, and a cheap bound then removes most of the other candidates before any costly test.
+        const int e0 = todo > 0 ? min(e_near, todo - 1) : -1;
+        PROF_T0(t_f);
+        if (__any(e0 >= 0)) {
+          if (e0 >= 0) {
+            const int ob = sm.list[e0 * kBlock + tid];
+            const DevObs O = obs[ob];
+            double t[3], pr[3] = {NAN, NAN, NAN}, pq[3] = {NAN, NAN, NAN}, wr[3], we[3], d;
+            to_box_frame(O, pc, t);
+            if (type == MVK_PRIM_BOX) {
+              const double a_[3] = {d0, d1, d2};
+              double Rr[9];
+              box_rel(O, PR, Rr);
+              d = box_box_sat<true>(t, Rr, a_, O.h, INFINITY);  // (<= 0: in contact, no points)
+              if (d > 0.0) d = box_box_exact_cp(t, Rr, a_, O.h, pr, pq);
+            } else {
+              d = narrow_cp(type, PR, d0, d1, d2, O, t, pr, pq, INFINITY);
+            }
+            to_world(O, pr, pq, wr, we);
+            gkey[lane] = ord_key(d + 0.0);
+            gob[lane] = static_cast<unsigned>(ob);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { pts[c * 64 + lane] = wr[c]; pts[(3 + c) * 64 + lane] = we[c]; }
+          }
+        }
+        PROF_CLK(4, t_f);
+        kmask[lane] = 0u;
+        number_pairs(static_cast<unsigned>(todo));
+        // the others: a pair whose centre distance less the primitive's bounding radius exceeds the owner's distance
+        // cannot realise the minimum (nor tie with it); the survivors are marked in the owner's mask (one bit per list
+        // entry: the list itself stays as it is for the other members of the group)
+        PROF_T0(t_a);
+#pragma unroll 1
+        for (unsigned base = 0; base < T; base += 64u) {
+          const unsigned i = base + static_cast<unsigned>(lane);
+          const bool act = i < T;
+          int src; unsigned e;
+          owner_of(i, act, src, e);
+          double spc[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) spc[c] = __shfl(pc[c], src);
+          const int se0 = __shfl(e0, src);
+          bool keep = false;
+          unsigned ob = 0u;
+          if (act && static_cast<int>(e) != se0) {
+            ob = sm.list[e * kBlock + wave_tid + src];
+            const DevObs& O = obs[ob];
+            double t[3];
+            to_box_frame(O, spc, t);
+            const double lim = (rb + fmax(ord_val(gkey[src]), 0.0)) * (1.0 + 1e-9) + 1e-9;
+            keep = point_box_dist2(t, O.h) <= lim * lim;
+          }
+          if (keep) __hip_atomic_fetch_or(&kmask[src], 1u << e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        PROF_CLK(3, t_a);
+        number_pairs(static_cast<unsigned>(__popc(kmask[lane])));
+#ifdef MVK_PROF_COUNTS
+        PROF_SUM(45, __popc(kmask[lane]));
+#endif
+      }
       if (type == MVK_PRIM_BOX) {
         // Every separated primitive needs at least one exact closest-point computation (24 edge-to-box closest
         // pairs, ~30x a separating-axis gap), so the order matters: pass A takes the gap of every candidate
@@ -4485,14 +4576,10 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
           }
         };
         if (flat) {
-          lds_u64* amin = reinterpret_cast<lds_u64*>(sm.ex_s2);  // [64] the smallest positive gap per owner (pass A; the batch buffer is idle)
-          amin[lane] = ord_key(INFINITY);
-          emin_l[lane] = 0xFFFFFFFFu;
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          PROF_T0(t_a);
+          // what round 0 and the bound left: the separating-axis gap against the owner's distance, contacts merged
+          // at once, and the exact closest points for the pairs whose gap still undercuts it
 #pragma unroll 1
-          for (unsigned base = 0; base < T; base += 64u) {  // pass A
+          for (unsigned base = 0; base < T; base += 64u) {
             const unsigned i = base + static_cast<unsigned>(lane);
             const bool act = i < T;
             int src; unsigned e;
@@ -4502,94 +4589,42 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
             for (int c = 0; c < 3; ++c) spc[c] = __shfl(pc[c], src);
 #pragma unroll
             for (int c = 0; c < 9; ++c) sPR[c] = __shfl(PR[c], src);
-            bool contact = false, pos = false;
-            double g = INFINITY;
-            int ob = 0;
-            if (act) {
-              ob = sm.list[e * kBlock + wave_tid + src];
-              const DevObs& O = obs[ob];
-              double Rr[9], t[3];
-              to_box_frame(O, spc, t);
-              box_rel(O, sPR, Rr);
-              const double cut = ord_val(amin[src]);
-              g = box_box_sat<true>(t, Rr, a, O.h, cut);
-              contact = g <= 0.0;
-              pos = !contact && g < cut;
-              if (pos) __hip_atomic_fetch_min(&amin[src], ord_key(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (pos && amin[src] == ord_key(g)) emin_l[src] = e;  // (equal gaps: either pair may go first)
-            merge(contact, src, g, ob, nan3, nan3);               // in contact: no points
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          PROF_CLK(3, t_a);
-          PROF_T0(t_f);
-          const unsigned emin = emin_l[lane];
-          {
-            const bool first = emin != 0xFFFFFFFFu && ord_val(amin[lane]) <= ord_val(gkey[lane]) + kSatSlack;
-            if (__any(first)) {
-              if (first) {  // every lane its own pair: the wave is full here
-                const int ob = sm.list[emin * kBlock + tid];
-                const DevObs O = obs[ob];
-                double Rr[9], t[3], pr[3], pq[3], wr[3], we[3];
-                to_box_frame(O, pc, t);
-                box_rel(O, PR, Rr);
-                const double d = box_box_exact_cp(t, Rr, a, O.h, pr, pq);
-                to_world(O, pr, pq, wr, we);
-                const unsigned long long k = ord_key(d + 0.0), gk = gkey[lane];
-                if (k < gk || (k == gk && static_cast<unsigned>(ob) < gob[lane])) {
-                  gkey[lane] = k;
-                  gob[lane] = static_cast<unsigned>(ob);
-#pragma unroll
-                  for (int c = 0; c < 3; ++c) { pts[c * 64 + lane] = wr[c]; pts[(3 + c) * 64 + lane] = we[c]; }
-                }
-              }
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          PROF_CLK(4, t_f);
-#pragma unroll 1
-          for (unsigned base = 0; base < T; base += 64u) {  // pass B
-            const unsigned i = base + static_cast<unsigned>(lane);
-            const bool act = i < T;
-            int src; unsigned e;
-            owner_of(i, act, src, e);
-            double spc[3], sPR[9];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) spc[c] = __shfl(pc[c], src);
-#pragma unroll
-            for (int c = 0; c < 9; ++c) sPR[c] = __shfl(PR[c], src);
-            bool need = false;
+            bool need = false, contact = false;
             double g = INFINITY, Rr[9], t[3];
             int ob = 0;
             rkey[lane] = ~0ull;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (act && e != emin_l[src]) {
-              ob = sm.list[e * kBlock + wave_tid + src];
+            if (act) {
+              ob = sm.list[nth_kept(kmask[src], e) * kBlock + wave_tid + src];
               const DevObs& O = obs[ob];
               to_box_frame(O, spc, t);
               box_rel(O, sPR, Rr);
               const double cut = ord_val(gkey[src]) + kSatSlack;  // (kSatSlack: the minimum does not depend on the order of the pairs)
-              g = box_box_sat<true>(t, Rr, a, O.h, cut);
+              // (a positive cutoff: the early exit on the face axes then only ever takes separated pairs)
+              g = box_box_sat<true>(t, Rr, a, O.h, fmax(cut, kSatSlack));
+              contact = g <= 0.0;
               need = g > 0.0 && g <= cut;
               if (need) __hip_atomic_fetch_min(&rkey[src], ord_key(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // per owner the pair with the smallest gap first (read before the merges below reuse rkey)
+            const bool first = need && rkey[src] == ord_key(g);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            merge(contact, src, g, ob, nan3, nan3);  // in contact: no points
+#ifdef MVK_PROF_COUNTS
+            PROF_SUM(46, need ? 1 : 0);
+#endif
             if (__any(need)) {
               auto deliver = [&](bool mine, double d, const double pr[3], const double pq[3]) {
                 double wr[3] = {NAN, NAN, NAN}, we[3] = {NAN, NAN, NAN};
                 if (mine) to_world(obs[ob], pr, pq, wr, we);
                 merge(mine, src, d, ob, wr, we);
               };
-              // per owner the pair with the smallest gap first; the others are re-tested against the result
-              const bool first = need && rkey[src] == ord_key(g);
-              __builtin_amdgcn_wave_barrier();
               run_cp(first, ob, Rr, t, deliver);
+              // the others are re-tested against the result
               const bool again = need && !first && g <= ord_val(gkey[src]) + kSatSlack;
               run_cp(again, ob, Rr, t, deliver);
             }
@@ -4670,7 +4705,7 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
           double d = INFINITY, wr[3] = {NAN, NAN, NAN}, we[3] = {NAN, NAN, NAN};
           int ob = 0;
           if (act) {
-            ob = sm.list[e * kBlock + wave_tid + src];
+            ob = sm.list[nth_kept(kmask[src], e) * kBlock + wave_tid + src];
             const DevObs O = obs[ob];
             double t[3], pr[3], pq[3];
             to_box_frame(O, spc, t);
@@ -4770,6 +4805,7 @@ avoid_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
         }
       }
       PROF_CLK(2, t_r);
+      }  // members
     }
   }
   PROF_ACC_FLUSH(40);

@@ -83,6 +83,21 @@ def broadphase_query(boxes, radius, points, cap=256):
     return counts, ids
 
 
+def grid_bounds_query(boxes, radius, pad, points, cap=1024):
+    """Host diagnostic (include/mvk_debug.h): a distance grid's list for each query point in list order, and per entry
+    the lower bound its group carries."""
+    lib = A.load()
+    arr, m = boxes_from_array(boxes)
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    counts = np.zeros(len(pts), np.int32)
+    ids = np.full((len(pts), cap), -1, np.int32)
+    bounds = np.full((len(pts), cap), np.nan, np.float32)
+    _check(lib, lib.mvk_debug_grid_bounds(arr, m, float(radius), float(pad), pts.ctypes.data_as(C.c_void_p), len(pts),
+                                          counts.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                                          bounds.ctypes.data_as(C.c_void_p), cap))
+    return counts, ids, bounds
+
+
 def far_grid_query(boxes, reach, margin, points, cap=1024):
     """Host diagnostic: ids the far grid lists for each query point ([n, 3]); counts -1 outside its volume."""
     lib = A.load()

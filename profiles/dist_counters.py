@@ -36,5 +36,6 @@ for name in sys.argv[1:] or ["c2", "c2k", "c3", "c5"]:
     b = [int(x) for x in buf]
     wv = max(b[47], 1)
     print(f"{name} avoid: per wave, us: candidates {b[40] / wv / 100:.1f}, drain {b[41] / wv / 100:.1f} (gaps {b[43] / wv / 100:.1f}, first exact {b[44] / wv / 100:.1f}), rows + stores {b[42] / wv / 100:.1f}; waves {wv}")
+    print(f"{name} avoid: after round 0 and the centre bound: {b[45] / max(b[36], 1):.2f} candidates per lane-prim left; exact closest-point pairs beyond round 0: {b[46] / max(b[36], 1):.3f} per lane-prim")
     print(f"{name} avoid: lane-prims {b[36]}, swept {b[37]} ({b[37] / max(b[36], 1):.4f}), overflow {b[38]} ({b[38] / max(b[36], 1):.4f}), mean candidates {b[39] / max(b[36], 1):.2f}", flush=True)
     eng.close()
