@@ -190,7 +190,27 @@ def distance_path(eng, w, d_soa, dev, workload=None):
                 row=torch.zeros(W * P, na, dtype=torch.float64, device=dev), lb=torch.zeros(P, na, dtype=torch.float64, device=dev),
                 ok=torch.zeros(na, dtype=torch.uint8, device=dev))
     avoid_ms = timed(lambda: eng.collision_avoidance_batch_dev(da, w.layout, outs))
-    return {"full_path": {"states": n, "ms": full_ms, "states_per_s": n / full_ms * 1e3,
+    # the fp32 variant of the same outputs (mvk_eval_batch_f32_dev): its rate, its stated tolerance, what was observed
+    f = dict(fl=torch.zeros(n, dtype=torch.uint8, device=dev), bd=torch.zeros(n, dtype=torch.uint8, device=dev),
+             md=torch.zeros(n, dtype=torch.float32, device=dev), mg=torch.zeros(n, dtype=torch.float32, device=dev),
+             me=torch.zeros(n, dtype=torch.float32, device=dev))
+    f32_ms = timed(lambda: eng.eval_batch_f32_dev(d_soa, w.layout, d_flags=f["fl"], d_min_dist=f["md"], d_margin=f["mg"],
+                                                  d_margin_err=f["me"], d_band=f["bd"]))
+    d64, m64, fl64 = md.cpu().numpy(), mg.cpu().numpy(), fl.cpu().numpy()
+    d32, m32, e32 = f["md"].cpu().numpy().astype(np.float64), f["mg"].cpu().numpy().astype(np.float64), f["me"].cpu().numpy().astype(np.float64)
+    fin = np.isfinite(d64)
+    x_max = float(np.abs(d_soa[0:3].cpu().numpy()).max())
+    enc = np.isfinite(e32) & np.isfinite(m64)
+    diff = (f["fl"].cpu().numpy() != fl64) & ~f["bd"].cpu().numpy().astype(bool)
+    fp32 = {"states": n, "ms": f32_ms, "states_per_s": n / f32_ms * 1e3, "dtype": "f32 broadphase + narrowphase and f32 statics with error bounds; f64 chain frames",
+            "tolerance": {"min_dist_abs_m": eng.f32_distance_tolerance(x_max),
+                          "min_dist_rule": "64 * 2^-24 * (largest |root coordinate| + reach + 1 m), per state (include/mvk.h)",
+                          "margin_rule": "per state: the f64 margin lies within margin +- margin_err (certified enclosure)"},
+            "observed": {"max_abs_err_min_dist_m": float(np.abs(d32[fin] - d64[fin]).max()) if fin.any() else None,
+                         "margin_enclosures_finite": float(enc.mean()), "margin_enclosures_violated": int(np.sum(np.abs(m32[enc] - m64[enc]) > e32[enc] + 4e-7 * np.maximum(np.abs(m64[enc]), 1.0))),
+                         "median_margin_err": float(np.median(e32[enc])) if enc.any() else None,
+                         "band_fraction": float(f["bd"].float().mean().item()), "flag_mismatches_outside_band": int(diff.sum())}}
+    return {"fp32_distances": fp32, "full_path": {"states": n, "ms": full_ms, "states_per_s": n / full_ms * 1e3,
                           "outputs": "flags, min_dist, margin per state + batch statistics",
                           "min_dist": stats["min_dist"], "min_margin": stats["min_margin"], "valid": stats["valid_count"],
                           "roofline": distance_roofline(workload, "distance_kernel", n, full_ms) if workload else None},

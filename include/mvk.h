@@ -385,6 +385,30 @@ int mvk_eval_batch(mvk_ctx* ctx, const double* soa, size_t n, size_t ld, int lay
 int mvk_eval_batch_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout,
                        uint8_t* d_flags, double* d_min_dist, double* d_margin, uint8_t* d_band,
                        const mvk_detail_out* d_detail, void* stream);
+/* The fp32 variant of the distance and margin outputs (the reference is all fp64, motion_planning.cpp:76-164; the
+ * north star asks for an fp32 variant reported with its own tolerance).  Same states, same verdict rule, outputs as
+ * floats:
+ *   d_min_dist   [n]  minimum signed distance with the narrowphase (separating-axis gaps, edge-to-box and
+ *                     segment-to-box distances) evaluated in fp32 on the fp32 copy of the boxes; the chain's frames
+ *                     stay fp64.  TOLERANCE, per state: |d_min_dist - min_dist(fp64)| <=
+ *                     mvk_f32_distance_tolerance(ctx, X) = MVK_F32_DIST_TOL_ULPS * 2^-24 * (X + reach + 1 m), X the
+ *                     largest |coordinate| of the state's root position and `reach` the robot's: 3e-5 m for a HYDRUS
+ *                     5 m from the origin.  Observed: 2e-7 .. 1e-6 m on the benchmark scenes
+ *                     (tests/test_gpu_f32_dist.py, bench.py's fp32_distances leg).  Scenes without a distance grid
+ *                     (< 64 boxes) and lanes whose candidate list overflowed are evaluated in fp64.
+ *   d_margin     [n]  midpoint of an ENCLOSURE of the fp64 stability margin computed in fp32 with running error
+ *                     bounds (the walk of MVK_PRECISION_F32_REFINED), d_margin_err [n] its half width: the fp64
+ *                     margin lies in [d_margin - d_margin_err, d_margin + d_margin_err]; +inf where a test could not
+ *                     be bounded in fp32 (a nearly singular wrench matrix).  The tolerance is per state, not a constant.
+ *   d_flags      [n]  finite && d_margin >= 0 && d_min_dist > 0 (as mvk_eval_batch_dev, on the fp32 values)
+ *   d_band       [n]  1 where the fp32 values cannot settle the verdict: |d_min_dist| <= max(eps_dist, the state's
+ *                     tolerance above), or the margin's enclosure reaches within eps_margin of zero.  Outside the band the
+ *                     flags equal the fp64 flags.
+ * Any output may be NULL.  Statistics (mvk_reduce_stats) afterwards are those of the fp32 values. */
+#define MVK_F32_DIST_TOL_ULPS 64.0
+double mvk_f32_distance_tolerance(mvk_ctx* ctx, double coord_abs_max);
+int mvk_eval_batch_f32_dev(mvk_ctx* ctx, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
+                           float* d_min_dist, float* d_margin, float* d_margin_err, uint8_t* d_band, void* stream);
 /* extrema over the last *_batch / eval call on this ctx (device reduction) */
 int mvk_reduce_stats(mvk_ctx* ctx, mvk_stats* out);
 

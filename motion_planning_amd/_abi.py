@@ -146,6 +146,8 @@ PROTOTYPES = {
     "mvk_mask_count_dev": (ip, [vp, sz, vp, vp]),
     "mvk_eval_batch": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, C.POINTER(DetailOut)]),
     "mvk_eval_batch_dev": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, C.POINTER(DetailOut), vp]),
+    "mvk_eval_batch_f32_dev": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, vp, vp]),
+    "mvk_f32_distance_tolerance": (d, [vp, d]),
     "mvk_reduce_stats": (ip, [vp, C.POINTER(Stats)]),
     "mvk_avoid_params_default": (ip, [C.POINTER(AvoidParams)]),
     "mvk_collision_avoidance_batch": (ip, [vp, vp, sz, sz, ip, C.POINTER(AvoidParams), C.POINTER(AvoidOut)]),

@@ -798,10 +798,13 @@ int prepare_queue(mvk_ctx* c, EvalArgs& a, uint64_t n) {
   return MVK_OK;
 }
 
+struct F32Out { float* min_dist; float* margin; float* margin_err; double dist_tol; };
+
 int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
                  uint64_t* d_mask, double* d_min_dist, double* d_margin, uint8_t* d_band,
                  const mvk_detail_out* det, bool force_full, hipStream_t s, uint32_t poll_seq = 0,
-                 const double* inline_rows = nullptr /* host rows of a single state, pitch 1: travel in the kernel arguments */) {
+                 const double* inline_rows = nullptr /* host rows of a single state, pitch 1: travel in the kernel arguments */,
+                 const F32Out* f32 = nullptr /* the fp32 variant of the distance / margin outputs */) {
   if (c && c->edges_pending) return fail(MVK_ERR_INVALID_ARG, "an edge check begun with mvk_check_motion_batch_begin is still in flight on this ctx: call mvk_check_motion_batch_end first");
   if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
   if (n == 0) return MVK_OK;
@@ -827,12 +830,20 @@ int run_eval_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layou
     want_detail = det->fc_t_min || det->fc_rp_min || det->thrust || det->rp_position_margin || det->cog || det->gimbal;
   }
   a.full = (force_full || d_min_dist || d_margin || d_band || want_detail) ? 1 : 0;
+  if (f32) {
+    a.full = 1;
+    a.f32_variant = 1;
+    a.min_dist_f32 = f32->min_dist;
+    a.margin_f32 = f32->margin;
+    a.margin_err_f32 = f32->margin_err;
+    a.eps_dist = std::fmax(a.eps_dist, f32->dist_tol);  // the band takes what the variant cannot tell from a contact
+  }
   c->stats_valid = false;
   if (a.full) {
     const uint64_t blocks = (n + kBlock - 1) / kBlock;
     // small batches with a collision stage: distance_small_kernel, a group of lanes per state (and a partial per
     // block of kBlock / kSmallGroup states)
-    a.small_full = (a.do_coll && a.n_obs > 0 && !d_mask && n <= c->small_full_max && c->small_full_enabled) ? 1 : 0;
+    a.small_full = (!f32 && a.do_coll && a.n_obs > 0 && !d_mask && n <= c->small_full_max && c->small_full_enabled) ? 1 : 0;
     if (a.small_full && n <= kFullOneLaunchMax) a.small_full = 2;  // walk 1 in the same launch, two states per block
     if (a.small_full == 2 && n == 1 && inline_rows) {
       a.inline_on = 1;
@@ -1294,6 +1305,22 @@ extern "C" int mvk_eval_batch_dev(mvk_ctx* c, const double* d_soa, size_t n, siz
                                   const mvk_detail_out* d_detail, void* stream) {
   return run_eval_dev(c, d_soa, n, ld, layout, d_flags, nullptr, d_min_dist, d_margin, d_band, d_detail, true,
                       static_cast<hipStream_t>(stream));
+}
+
+// fp32 variant of the distance / margin outputs (include/mvk.h): model32_kernel + distance_kernel<.., true>
+extern "C" double mvk_f32_distance_tolerance(mvk_ctx* c, double coord_abs_max) {
+  if (!c || !(coord_abs_max >= 0.0)) return NAN;
+  // one fp32 rounding is 2^-24 relative to a coordinate of the state's primitives or of the boxes near them
+  // (|root position| + the robot's reach, + 1 m for the boxes' own extent); the narrowphase chains a few dozen
+  return MVK_F32_DIST_TOL_ULPS * 5.9604644775390625e-8 * (coord_abs_max + c->extras.reach + 1.0);
+}
+
+extern "C" int mvk_eval_batch_f32_dev(mvk_ctx* c, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
+                                      float* d_min_dist, float* d_margin, float* d_margin_err, uint8_t* d_band, void* stream) {
+  if (!c) return fail(MVK_ERR_INVALID_ARG, "null ctx");
+  const F32Out f32{d_min_dist, d_margin, d_margin_err, 0.0};  // (the band's distance tolerance is per state: distance_kernel)
+  return run_eval_dev(c, d_soa, n, ld, layout, d_flags, nullptr, nullptr, nullptr, d_band, nullptr, true, static_cast<hipStream_t>(stream), 0,
+                      nullptr, &f32);
 }
 
 namespace {

@@ -177,6 +177,11 @@ struct EvalArgs {
   double* min_dist;
   double* margin;
   uint8_t* band;
+  // fp32 variant of the distance / margin outputs (mvk_eval_batch_f32_dev): model32_kernel + distance_kernel<.., true>
+  int f32_variant = 0;
+  float* min_dist_f32 = nullptr;    // [n]
+  float* margin_f32 = nullptr;      // [n] midpoint of the fp32 enclosure of the margin
+  float* margin_err_f32 = nullptr;  // [n] its half width (+inf: a test could not be bounded in fp32)
   double* fc_t_min;
   double* fc_rp_min;
   double* thrust;

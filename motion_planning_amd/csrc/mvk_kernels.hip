@@ -353,6 +353,107 @@ DEV double box_edges_to_box2(const double c[3], const double R[9], const double 
 }
 
 
+// ---- the same narrowphase in fp32 (the fp32 variant of the distance outputs, mvk_eval_batch_f32_dev): one rounding
+// of 2^-24 relative per operation on box-frame coordinates of a few metres, i.e. errors of ~1e-6 m; the tolerance the
+// variant is reported with is stated in include/mvk.h and measured in tests/test_gpu_f32_dist.py ----
+DEV float excess_f(float x, float h) { return x > h ? x - h : (x < -h ? x + h : 0.0f); }
+DEV float excess_abs_f(float x, float h) { return fmaxf(fabsf(x) - h, 0.0f); }
+DEV float seg_grad_f(const float p0[3], const float d[3], const float h[3], float t) {
+  float g = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g = fmaf(d[k], excess_f(fmaf(t, d[k], p0[k]), h[k]), g);
+  return g;
+}
+DEV float seg_box_dist2_f(const float p0[3], const float d[3], const float h[3]) {
+  const float g0 = seg_grad_f(p0, d, h, 0.0f), g1 = seg_grad_f(p0, d, h, 1.0f);
+  float tlo = 0.0f, glo = g0, thi = 1.0f, ghi = g1;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float inv = __frcp_rn(d[k]);  // inf for d[k] == 0: no breakpoint on that axis
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const float t = ((sg ? -h[k] : h[k]) - p0[k]) * inv;
+      if (t > 0.0f && t < 1.0f) {  // false for NaN / inf
+        const float g = seg_grad_f(p0, d, h, t);
+        if (g < 0.0f) {
+          if (t > tlo) { tlo = t; glo = g; }
+        } else if (t < thi) { thi = t; ghi = g; }
+      }
+    }
+  }
+  float ts = (ghi > glo) ? fmaf(thi - tlo, -glo / (ghi - glo), tlo) : tlo;
+  ts = (g1 <= 0.0f) ? 1.0f : ts;
+  ts = (g0 >= 0.0f) ? 0.0f : ts;
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float e = excess_abs_f(fmaf(ts, d[k], p0[k]), h[k]);
+    s = fmaf(e, e, s);
+  }
+  return s;
+}
+// largest metric separating-axis gap (box_box_sat<true>), the nine edge axes skipped once the face axes reach cutoff
+// recheck: the pair is in contact by the axes taken and an ill-conditioned edge axis was left out -- the penetration
+// depth may hang on it, the caller repeats the pair in fp64
+DEV float box_box_sat_f(const float t[3], const float R[9], const float a[3], const float b[3], float cutoff, bool& recheck) {
+  float Q[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Q[i] = fabsf(R[i]);
+  float best = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float g = fabsf(t[i]) - (b[i] + fmaf(a[0], Q[3 * i], fmaf(a[1], Q[3 * i + 1], a[2] * Q[3 * i + 2])));
+    best = fmaxf(best, g);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float proj = fmaf(t[0], R[j], fmaf(t[1], R[3 + j], t[2] * R[6 + j]));
+    const float g = fabsf(proj) - (a[j] + fmaf(b[0], Q[j], fmaf(b[1], Q[3 + j], b[2] * Q[6 + j])));
+    best = fmaxf(best, g);
+  }
+  recheck = false;
+  if (best >= cutoff) return best;
+  bool left_out = false;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      // |b_i x a_j|^2 from the two other components of a_j (1 - R_ij^2 would cancel)
+      const float len2 = fmaf(R[3 * i1 + j], R[3 * i1 + j], R[3 * i2 + j] * R[3 * i2 + j]);
+      const float rb = fmaf(b[i1], Q[3 * i2 + j], b[i2] * Q[3 * i1 + j]);
+      const float ra = fmaf(a[j1], Q[3 * i + j2], a[j2] * Q[3 * i + j1]);
+      float g = fabsf(fmaf(t[i2], R[3 * i1 + j], -t[i1] * R[3 * i2 + j])) - (ra + rb);
+      g = g * __frsqrt_rn(len2);
+      // (nearly) parallel edges: 1 / |axis| amplifies the roundings of the numerator (1e-7 m) -- beyond ten times the
+      // axis is left out, which only ever lowers the gap (a lower bound stays one) and sends the pair to the edge distances
+      left_out = left_out || (len2 < 1e-2f && len2 >= 1e-12f);
+      g = (len2 < 1e-2f) ? -INFINITY : g;
+      best = fmaxf(best, g);
+    }
+  recheck = left_out && best <= 0.0f;
+  return best;
+}
+DEV float box_edge_to_box2_f(int e, const float c[3], const float R[9], const float a[3], const float b[3]) {
+  const int ax = e >> 2;
+  const float su = (e & 1) ? 1.0f : -1.0f, sv = (e & 2) ? 1.0f : -1.0f;
+  float p0[3], d[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float cx = R[3 * k], cy = R[3 * k + 1], cz = R[3 * k + 2];
+    const float Aax = ax == 0 ? cx : (ax == 1 ? cy : cz);
+    const float Au = ax == 0 ? cy : (ax == 1 ? cz : cx);
+    const float Av = ax == 0 ? cz : (ax == 1 ? cx : cy);
+    const float hax = ax == 0 ? a[0] : (ax == 1 ? a[1] : a[2]);
+    const float hu = ax == 0 ? a[1] : (ax == 1 ? a[2] : a[0]);
+    const float hv = ax == 0 ? a[2] : (ax == 1 ? a[0] : a[1]);
+    const float mid = fmaf(su * hu, Au, fmaf(sv * hv, Av, c[k]));
+    p0[k] = fmaf(-hax, Aax, mid);
+    d[k] = 2.0f * hax * Aax;
+  }
+  return seg_box_dist2_f(p0, d, b);
+}
+
 // ---- closest points (collision-avoidance rows) -----------------
 // as seg_box_dist2, also returning the point on the segment (y) and on the box (z), box frame
 DEV double seg_box_closest2(const double p0[3], const double d[3], const double h[3], double y[3], double z[3]) {
@@ -878,9 +979,10 @@ constexpr float kF32U = 5.9604645e-8f;  // 2^-24
 // returns 1: certainly stable, 0: certainly unstable, -1: uncertain.  Leaves the joints' fp32 cos/sin in
 // csf[(2j) * kBlock + tid], csf[(2j+1) * kBlock + tid] for walk 2.  Rf = float(Rw).
 // dbg (nullable): [0] smallest s - e, [1] smallest s + e over the tests that could be bounded, [2] 1 when a test could not
+// mdbg (nullable): the same two for the metric slacks -- an enclosure of the full path's fp64 margin when dbg[2] == 0
 template <int ROBOT, int NL>
 DEV int model_update_f32(const EvalArgs& A, const DevExtras* __restrict__ X, const double* st, const float Rf[9],
-                         lds_float* csf, float* dbg) {
+                         lds_float* csf, float* dbg, float* mdbg = nullptr) {
   using S = Shape<ROBOT, NL>;
   constexpr int NS = S::kSeg, NJ = S::kJoint, D = S::kDof;
   const ModelF32& F = X->f32;
@@ -981,7 +1083,15 @@ DEV int model_update_f32(const EvalArgs& A, const DevExtras* __restrict__ X, con
     Vm = fmaxf(Vm, fmaxf(fabsf(V[i][0]), fmaxf(fabsf(V[i][1]), fabsf(V[i][2]))));
   }
   float lo = INFINITY, hi = INFINITY;  // smallest s - e, smallest s + e
-  auto test = [&](float sl, float e) { lo = fminf(lo, sl - e); hi = fminf(hi, sl + e); };
+  // ... and the same enclosure of the METRIC slacks (the margin of the full path: the feasible-control tests there are
+  // distance - threshold, here distance * |n| - threshold * |n|): numerator sl +- e over denominator den +- e_den
+  float lo_m = INFINITY, hi_m = INFINITY;
+  auto test = [&](float sl, float e, float den = 1.0f, float e_den = 0.0f) {
+    lo = fminf(lo, sl - e); hi = fminf(hi, sl + e);
+    const float a = sl - e, b = sl + e, dl = fmaxf(den - e_den, 1e-30f), dh = den + e_den;
+    lo_m = fminf(lo_m, (a >= 0.0f ? a / dh : a / dl) - 4.0f * kF32U * fabsf(a / dl));
+    hi_m = fminf(hi_m, (b >= 0.0f ? b / dl : b / dh) + 4.0f * kF32U * fabsf(b / dl));
+  };
 
   // ---- static thrust: lambda = A^T (A A^T)^-1 b on rows {fz, tx, ty, (tz)} ----------------
   // First-order perturbation of the minimum-norm solution for A -> A + E, |E_ri| <= dA_ri:
@@ -1139,7 +1249,7 @@ DEV int model_update_f32(const EvalArgs& A, const DevExtras* __restrict__ X, con
         const float e = fmaf(half_fmax, 2.0f * e_sum + 8.0f * kF32U * (sabs + fabsf(ssum)), F.fc_t_thre * e_nn);
         // the fp64 rule "|n| < 1e-5 -> distance 0" must be decidable as well
         if (!(nn > 1e-5f + 2.0f * e_nn)) unc = true;
-        else test(dist_n - F.fc_t_thre * nn, e);
+        else test(dist_n - F.fc_t_thre * nn, e, nn, e_nn);
       }
   }
   // ---- roll / pitch distances ----
@@ -1158,7 +1268,7 @@ DEV int model_update_f32(const EvalArgs& A, const DevExtras* __restrict__ X, con
       const float na = sqrtf(na2);
       const float e = half_fmax * (2.0f * NL) * e_c + F.fc_rp_thre * 2.0f * dV;
       if (!(na > 1e-5f + 4.0f * dV)) unc = true;
-      else test(dist_n - F.fc_rp_thre * na, e);
+      else test(dist_n - F.fc_rp_thre * na, e, na, 4.0f * dV);
     }
   }
   // ---- EDF overlap (gimbal models) ----
@@ -1175,6 +1285,7 @@ DEV int model_update_f32(const EvalArgs& A, const DevExtras* __restrict__ X, con
       }
   }
   if (dbg) { dbg[0] = lo; dbg[1] = hi; dbg[2] = unc ? 1.0f : 0.0f; }
+  if (mdbg) { mdbg[0] = lo_m; mdbg[1] = hi_m; }
   if (hi < 0.0f) return 0;            // some test certainly fails (NaN compares false: uncertain)
   if (!unc && lo > 0.0f) return 1;    // every test certainly passes
   return -1;
@@ -1271,6 +1382,7 @@ DEV double box_box_exact(const double t[3], const double Rr[9], const double a[3
 // pair is therefore skipped only when its gap exceeds the running minimum by kSatSlack, which makes the minimum
 // independent of the order (distance_kernel and distance_small_kernel visit the pairs in different orders).
 constexpr double kSatSlack = 1e-9;
+constexpr double kSatSlackF32 = 2e-6;  // the fp32 variant's: a few fp32 roundings of a gap of a metre
 
 // exact test of one primitive against one box (primitive kind is wave-uniform); t = primitive
 // centre in the box frame.  SIGNED: signed distance; otherwise only the sign is meaningful.
@@ -2100,7 +2212,10 @@ DEV double ord_val(unsigned long long k) {
 // ------------------------------------------------------------------------
 // full path: exact minimum distance over every (primitive, box) pair
 // ------------------------------------------------------------------------
-template <int ROBOT, int NL>
+// F32N: the fp32 variant of the distance output -- the flat drains (every pair of a scene with a distance grid, bar the
+// lanes whose list overflowed) take the box from the fp32 copy and run the separating-axis gap, the edge-to-box and the
+// segment-to-box distances in fp32; frames, broadphase bounds and the merge of the minima are as in the fp64 form.
+template <int ROBOT, int NL, bool F32N = false>
 DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
                         const DevObs* __restrict__ obs, const double pos[3], const double Rw[9], const Smem& sm,
                         bool live) {
@@ -2368,24 +2483,44 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { it_[c] = sm.ex_item[pr * kExactItem + 9 + c]; ih[c] = sm.ex_item[pr * kExactItem + 12 + c]; }
                 const bool second = ed >= 12;
-                double cR[9], cc[3], ca[3], cb[3];
+                double s2;
+                if constexpr (F32N) {
+                  float fR[9], ft[3], fh[3], fa[3], cR[9], cc[3], ca[3], cb[3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
+                  for (int c = 0; c < 9; ++c) fR[c] = static_cast<float>(iR[c]);
 #pragma unroll
-                  for (int c = 0; c < 3; ++c) cR[3 * r + c] = second ? iR[3 * c + r] : iR[3 * r + c];
-                  const double tb = -fma(iR[r], it_[0], fma(iR[3 + r], it_[1], iR[6 + r] * it_[2]));
-                  cc[r] = second ? tb : it_[r];
-                  ca[r] = second ? ih[r] : a[r];
-                  cb[r] = second ? a[r] : ih[r];
+                  for (int c = 0; c < 3; ++c) { ft[c] = static_cast<float>(it_[c]); fh[c] = static_cast<float>(ih[c]); fa[c] = static_cast<float>(a[c]); }
+#pragma unroll
+                  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) cR[3 * r + c] = second ? fR[3 * c + r] : fR[3 * r + c];
+                    const float tb = -fmaf(fR[r], ft[0], fmaf(fR[3 + r], ft[1], fR[6 + r] * ft[2]));
+                    cc[r] = second ? tb : ft[r];
+                    ca[r] = second ? fh[r] : fa[r];
+                    cb[r] = second ? fa[r] : fh[r];
+                  }
+                  s2 = static_cast<double>(box_edge_to_box2_f(second ? ed - 12 : ed, cc, cR, ca, cb));
+                } else {
+                  double cR[9], cc[3], ca[3], cb[3];
+#pragma unroll
+                  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) cR[3 * r + c] = second ? iR[3 * c + r] : iR[3 * r + c];
+                    const double tb = -fma(iR[r], it_[0], fma(iR[3 + r], it_[1], iR[6 + r] * it_[2]));
+                    cc[r] = second ? tb : it_[r];
+                    ca[r] = second ? ih[r] : a[r];
+                    cb[r] = second ? a[r] : ih[r];
+                  }
+                  s2 = box_edge_to_box2(second ? ed - 12 : ed, cc, cR, ca, cb);
                 }
-                const double s2 = box_edge_to_box2(second ? ed - 12 : ed, cc, cR, ca, cb);
                 __hip_atomic_fetch_min(&sm.ex_res[pr], static_cast<unsigned long long>(__double_as_longlong(s2)), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WAVEFRONT);
               }
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
               __builtin_amdgcn_wave_barrier();
               if (mine)
-                __hip_atomic_fetch_min(&sm.mres[src], ord_key(sqrt(__longlong_as_double(static_cast<long long>(sm.ex_res[rank])))),
+                __hip_atomic_fetch_min(&sm.mres[src], ord_key(F32N ? static_cast<double>(sqrtf(static_cast<float>(__longlong_as_double(static_cast<long long>(sm.ex_res[rank])))))
+                                                                    : sqrt(__longlong_as_double(static_cast<long long>(sm.ex_res[rank])))),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
               pend &= ~__ballot(mine);
               __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2420,11 +2555,45 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
             __builtin_amdgcn_wave_barrier();
             if (act) {
               const int ob = sm.list[e * kBlock + wave_tid + src];
+              const double cut = ord_val(sm.mres[src]) + (F32N ? kSatSlackF32 : kSatSlack);
+              const double reach_m = own + fmax(cut, 0.0);
+              if constexpr (F32N) {
+                const DevObsF Of = A.obsf[ob];
+                const float dx = static_cast<float>(spc[0]) - Of.c[0], dy = static_cast<float>(spc[1]) - Of.c[1], dz = static_cast<float>(spc[2]) - Of.c[2];
+                float tf[3], Rf[9], fP[9];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tf[c] = fmaf(Of.R[c], dx, fmaf(Of.R[3 + c], dy, Of.R[6 + c] * dz));
+                const float rm = static_cast<float>(reach_m) * 1.00001f + 1e-6f;
+                const float c2 = fmaf(excess_abs_f(tf[0], Of.h[0]), excess_abs_f(tf[0], Of.h[0]),
+                                      fmaf(excess_abs_f(tf[1], Of.h[1]), excess_abs_f(tf[1], Of.h[1]), excess_abs_f(tf[2], Of.h[2]) * excess_abs_f(tf[2], Of.h[2])));
+                if (single || c2 <= rm * rm) {
+#pragma unroll
+                  for (int c = 0; c < 9; ++c) fP[c] = static_cast<float>(sPR[c]);
+#pragma unroll
+                  for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Rf[3 * r + c] = fmaf(Of.R[r], fP[c], fmaf(Of.R[3 + r], fP[3 + c], Of.R[6 + r] * fP[6 + c]));
+                  const float af[3] = {static_cast<float>(a[0]), static_cast<float>(a[1]), static_cast<float>(a[2])};
+                  bool recheck;
+                  g = static_cast<double>(box_box_sat_f(tf, Rf, af, Of.h, static_cast<float>(cut), recheck));
+#pragma unroll
+                  for (int c = 0; c < 9; ++c) Rr[c] = static_cast<double>(Rf[c]);
+#pragma unroll
+                  for (int c = 0; c < 3; ++c) { t[c] = static_cast<double>(tf[c]); h[c] = static_cast<double>(Of.h[c]); }
+                  if (recheck) {  // (a contact between nearly parallel edges: rare, and its depth needs the axis fp32 cannot resolve)
+                    const DevObs& O = obs[ob];
+                    double t64[3], R64[9];
+                    to_box_frame(O, spc, t64);
+                    box_rel(O, sPR, R64);
+                    g = box_box_sat<true>(t64, R64, a, O.h, cut);
+                  }
+                  if (g <= 0.0) __hip_atomic_fetch_min(&sm.mres[src], ord_key(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                  else need = g < cut;
+                }
+              } else {
               const DevObs& O = obs[ob];
               to_box_frame(O, spc, t);
               h[0] = O.h[0]; h[1] = O.h[1]; h[2] = O.h[2];
-              const double cut = ord_val(sm.mres[src]) + kSatSlack;
-              const double reach_m = own + fmax(cut, 0.0);
               if (single || point_box_dist2(t, h) <= reach_m * reach_m) {
                 box_rel(O, sPR, Rr);
                 g = box_box_sat<true>(t, Rr, a, h, cut);
@@ -2434,13 +2603,14 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
                 if (g <= 0.0) __hip_atomic_fetch_min(&sm.mres[src], ord_key(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 else need = g < cut;
               }
+              }
               if (need) __hip_atomic_fetch_min(&sm.gmin[src], static_cast<unsigned long long>(__double_as_longlong(g)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const bool first = need && static_cast<unsigned long long>(__double_as_longlong(g)) == sm.gmin[src];
             run_exact(first, src, Rr, t, h);
-            const bool again = need && !first && g < ord_val(sm.mres[src]) + kSatSlack;
+            const bool again = need && !first && g < ord_val(sm.mres[src]) + (F32N ? kSatSlackF32 : kSatSlack);
             run_exact(again, src, Rr, t, h);
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2565,17 +2735,42 @@ DEV double collide_full(const EvalArgs& A, const mvk_model* __restrict__ M, cons
             for (int c = 0; c < 3; ++c) sPR[3 * c + 2] = __shfl(PR[3 * c + 2], src);  // (a capsule's axis: all narrow() reads)
             if (act) {
               const int ob = sm.list[e * kBlock + wave_tid + src];
+              double d = INFINITY;
+              if constexpr (F32N) {
+                const DevObsF Of = A.obsf[ob];
+                const float dx = static_cast<float>(spc[0]) - Of.c[0], dy = static_cast<float>(spc[1]) - Of.c[1], dz = static_cast<float>(spc[2]) - Of.c[2];
+                float tf[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tf[c] = fmaf(Of.R[c], dx, fmaf(Of.R[3 + c], dy, Of.R[6 + c] * dz));
+                const float c2 = fmaf(excess_abs_f(tf[0], Of.h[0]), excess_abs_f(tf[0], Of.h[0]),
+                                      fmaf(excess_abs_f(tf[1], Of.h[1]), excess_abs_f(tf[1], Of.h[1]), excess_abs_f(tf[2], Of.h[2]) * excess_abs_f(tf[2], Of.h[2])));
+                if (type == MVK_PRIM_SPHERE) {
+                  d = static_cast<double>(sqrtf(c2) - static_cast<float>(d0));
+                } else {
+                  const float rm = static_cast<float>(own + fmax(ord_val(sm.mres[src]) + kSatSlackF32, 0.0)) * 1.00001f + 1e-6f;
+                  if (single || c2 <= rm * rm) {  // a capsule: its axis (third column of the pose) into the box frame
+                    const float ax[3] = {static_cast<float>(sPR[2]), static_cast<float>(sPR[5]), static_cast<float>(sPR[8])};
+                    const float hl = static_cast<float>(d1);
+                    float av[3], p0[3], dd[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) av[c] = fmaf(Of.R[c], ax[0], fmaf(Of.R[3 + c], ax[1], Of.R[6 + c] * ax[2]));
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { p0[c] = fmaf(-hl, av[c], tf[c]); dd[c] = 2.0f * hl * av[c]; }
+                    d = static_cast<double>(sqrtf(seg_box_dist2_f(p0, dd, Of.h)) - static_cast<float>(d0));
+                  }
+                }
+              } else {
               const DevObs& O = obs[ob];
               double t[3];
               to_box_frame(O, spc, t);
               const double h[3] = {O.h[0], O.h[1], O.h[2]};
               const double c2 = point_box_dist2(t, h);
-              double d = INFINITY;
               if (type == MVK_PRIM_SPHERE) {
                 d = sqrt(c2) - d0;
               } else {
                 const double reach_m = own + fmax(ord_val(sm.mres[src]) + kSatSlack, 0.0);
                 if (single || c2 <= reach_m * reach_m) d = narrow<true>(type, sPR, d0, d1, d2, O, t, INFINITY);
+              }
               }
               __hip_atomic_fetch_min(&sm.mres[src], ord_key(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
@@ -3570,13 +3765,15 @@ constexpr int kFullRecMargin = 0, kFullRecLamMin = 1, kFullRecLamMax = 2, kFullR
 
 // verdict, band, per-state outputs and the block's partial statistics (motion_planning.cpp:615-632 extrema)
 DEV void full_finish(const EvalArgs& A, uint64_t gi, bool in_range, bool finite, double margin, double lam_min, double lam_max,
-                     double rp_margin, double mind, bool stable) {
+                     double rp_margin, double mind, bool stable, double margin_err = 0.0, double dist_tol = 0.0) {
   StateOut o;
   o.margin = margin; o.lam_min = lam_min; o.lam_max = lam_max; o.rp_margin = rp_margin; o.stable = stable;
   o.min_dist = (A.do_coll && finite) ? mind : INFINITY;
   o.collision = A.do_coll && (mind <= 0.0);
   o.valid = finite && (!A.do_stab || o.stable) && !o.collision;
-  o.band = !finite || (A.do_stab && fabs(o.margin) <= A.eps_margin) || (A.do_coll && fabs(o.min_dist) <= A.eps_dist);
+  // (fp32 variant: margin_err is the half width of the margin's enclosure, eps_dist the variant's distance tolerance)
+  o.band = !finite || (A.do_stab && (margin_err > 0.0 ? !(fabs(o.margin) > A.eps_margin + margin_err) : fabs(o.margin) <= A.eps_margin)) ||
+           (A.do_coll && fabs(o.min_dist) <= fmax(A.eps_dist, dist_tol));
   if (!finite) { o.margin = -INFINITY; o.min_dist = NAN; o.stable = false; o.collision = false; }
 
   if (in_range) {
@@ -3584,6 +3781,7 @@ DEV void full_finish(const EvalArgs& A, uint64_t gi, bool in_range, bool finite,
     if (A.band) A.band[gi] = o.band ? 1 : 0;
     if (A.min_dist) A.min_dist[gi] = o.min_dist;
     if (A.margin) A.margin[gi] = o.margin;
+    if (A.min_dist_f32) A.min_dist_f32[gi] = static_cast<float>(o.min_dist);
   }
   if (A.mask) {
     const unsigned long long bal = __ballot(in_range && o.valid);
@@ -3694,7 +3892,69 @@ model_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras*
 #define MVK_DISTANCE_WAVES 2
 #endif
 constexpr int kDistanceWaves = MVK_DISTANCE_WAVES;
+// model32_kernel: walk 1 of the fp32 variant (mvk_eval_batch_f32_dev).  The statics run in fp32 with their error bounds
+// (model_update_f32), which enclose the fp64 margin: [lo, hi] -> midpoint and half width, written as floats; the
+// verdict takes the midpoint, the band every state whose enclosure reaches within eps_margin of zero.  The hand-off
+// rows for the distance stage carry fp64 cos/sin of the joints (the chain's frames are then as in the fp64 path: the
+// fp32 part of the distance stage is its broadphase and its narrowphase), the midpoint, the half width and 'finite'.
 template <int ROBOT, int NL>
+__global__ void __launch_bounds__(kBlock, 2)
+model32_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X) {
+  using S = Shape<ROBOT, NL>;
+  constexpr int NJ = S::kJoint;
+  __shared__ float sm_csf[2 * NJ * kBlock];
+  const uint64_t gi = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool in_range = gi < A.n;
+  const uint64_t li = in_range ? gi : (A.n - 1);
+  double st[7 + NJ];
+  uint64_t edge;
+  int step;
+  fetch_state<NJ, false, true>(A, li, st, edge, step);
+  double Rw[9];
+  quat_to_mat(st[3], st[4], st[5], st[6], Rw);
+  bool finite = true;
+#pragma unroll
+  for (int k = 0; k < 7 + NJ; ++k) finite = finite && isfinite(st[k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) finite = finite && isfinite(Rw[k]);
+  float Rf[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rf[k] = static_cast<float>(Rw[k]);
+  float mid = INFINITY, err = 0.0f;
+  if (A.do_stab) {
+    float dbg[3], mdbg[2];
+    (void)model_update_f32<ROBOT, NL>(A, X, st, Rf, (lds_float*)sm_csf, dbg, mdbg);
+    mid = 0.5f * (mdbg[0] + mdbg[1]);
+    err = 0.5f * (mdbg[1] - mdbg[0]) + 2.0f * kF32U * fabsf(mid);
+    if (dbg[2] != 0.0f || !(err < INFINITY) || !(fabsf(mid) < INFINITY)) { err = INFINITY; mid = isfinite(mid) ? mid : 0.0f; }  // not bounded in fp32
+  }
+  if (!finite) { mid = -INFINITY; err = 0.0f; }
+  if (in_range) {
+    if (A.margin_f32) A.margin_f32[gi] = mid;
+    if (A.margin_err_f32) A.margin_err_f32[gi] = err;
+  }
+  const double margin = static_cast<double>(mid), margin_err = static_cast<double>(err);
+  if (A.full_rec) {  // the collision stage follows in distance_kernel
+    double* __restrict__ rec = A.full_rec;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      double sj, cj;
+      sincos_cw(st[7 + j], sj, cj);
+      rec[static_cast<uint64_t>(2 * j) * A.full_rec_ld + gi] = cj;
+      rec[static_cast<uint64_t>(2 * j + 1) * A.full_rec_ld + gi] = sj;
+    }
+    double* __restrict__ sc = rec + static_cast<uint64_t>(2 * NJ) * A.full_rec_ld;
+    sc[static_cast<uint64_t>(kFullRecMargin) * A.full_rec_ld + gi] = margin;
+    sc[static_cast<uint64_t>(kFullRecLamMin) * A.full_rec_ld + gi] = margin_err;  // (this variant: the half width rides in the thrust row)
+    sc[static_cast<uint64_t>(kFullRecLamMax) * A.full_rec_ld + gi] = NAN;
+    sc[static_cast<uint64_t>(kFullRecRp) * A.full_rec_ld + gi] = NAN;
+    sc[static_cast<uint64_t>(kFullRecFinite) * A.full_rec_ld + gi] = finite ? 1.0 : 0.0;
+    return;
+  }
+  full_finish(A, gi, in_range, finite, margin, NAN, NAN, NAN, INFINITY, margin >= 0.0, margin_err);
+}
+
+template <int ROBOT, int NL, bool F32N = false>
 __global__ void __launch_bounds__(kBlock, kDistanceWaves)
 distance_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtras* __restrict__ X,
                 const DevObs* __restrict__ obs) {
@@ -3727,10 +3987,16 @@ distance_kernel(const EvalArgs A, const mvk_model* __restrict__ M, const DevExtr
   const bool finite = sc[static_cast<uint64_t>(kFullRecFinite) * A.full_rec_ld + gi] != 0.0;
 
   double mind = INFINITY;
-  if (__any(finite)) mind = collide_full<ROBOT, NL>(A, M, X, obs, st, Rw, sm, finite);
+  if (__any(finite)) mind = collide_full<ROBOT, NL, F32N>(A, M, X, obs, st, Rw, sm, finite);
   PROF_WAVE(28);
 
   const double margin = sc[static_cast<uint64_t>(kFullRecMargin) * A.full_rec_ld + gi];
+  if constexpr (F32N) {  // (model32_kernel's rows: the thrust row carries the margin's half width)
+    // the variant's distance tolerance at this state (include/mvk.h: mvk_f32_distance_tolerance)
+    const double tol = MVK_F32_DIST_TOL_ULPS * 5.9604644775390625e-8 * (fmax(fabs(st[0]), fmax(fabs(st[1]), fabs(st[2]))) + X->reach + 1.0);
+    full_finish(A, gi, in_range, finite, margin, NAN, NAN, NAN, mind, margin >= 0.0, sc[static_cast<uint64_t>(kFullRecLamMin) * A.full_rec_ld + gi], tol);
+    return;
+  }
   full_finish(A, gi, in_range, finite, margin, sc[static_cast<uint64_t>(kFullRecLamMin) * A.full_rec_ld + gi],
               sc[static_cast<uint64_t>(kFullRecLamMax) * A.full_rec_ld + gi], sc[static_cast<uint64_t>(kFullRecRp) * A.full_rec_ld + gi],
               mind, margin >= 0.0);
@@ -5290,6 +5556,13 @@ int launch_shape(const EvalArgs& a, bool edge_mode, hipStream_t s, hipEvent_t* e
     const dim3 gs(static_cast<unsigned>((a.n + 1) / 2));
     hipLaunchKernelGGL((full_small_kernel<ROBOT, NL>), gs, b, 0, s, a, a.model, a.extras, a.obs);
     if (ev) { (void)hipEventRecord(ev[1], s); (void)hipEventRecord(ev[2], s); }
+    return hipGetLastError();
+  }
+  if (a.full && !edge_mode && a.f32_variant) {
+    hipLaunchKernelGGL((model32_kernel<ROBOT, NL>), g, b, 0, s, a, a.model, a.extras);
+    if (ev) (void)hipEventRecord(ev[1], s);
+    if (a.full_rec) hipLaunchKernelGGL((distance_kernel<ROBOT, NL, true>), g, b, 0, s, a, a.model, a.extras, a.obs);
+    if (ev) (void)hipEventRecord(ev[2], s);
     return hipGetLastError();
   }
   if (a.full && !edge_mode) {

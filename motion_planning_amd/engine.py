@@ -332,6 +332,20 @@ class Engine:
                                                          self._dp(d_min_dist), self._dp(d_margin), self._dp(d_band),
                                                          self._stream(stream)))
 
+    def eval_batch_f32_dev(self, d_soa, layout, d_flags=None, d_min_dist=None, d_margin=None, d_margin_err=None, d_band=None,
+                           stream=None):
+        """the fp32 variant of the distance / margin outputs (mvk_eval_batch_f32_dev): float32 device tensors"""
+        rows, n = d_soa.shape
+        ld = d_soa.stride(0)
+        assert d_soa.stride(1) == 1 and rows == self.state_dim(layout)
+        _check(self.lib, self.lib.mvk_eval_batch_f32_dev(self.ctx, self._dp(d_soa), n, ld, layout, self._dp(d_flags),
+                                                         self._dp(d_min_dist), self._dp(d_margin), self._dp(d_margin_err),
+                                                         self._dp(d_band), self._stream(stream)))
+
+    def f32_distance_tolerance(self, coord_abs_max):
+        """the fp32 variant's distance tolerance for a state whose root position has that largest |coordinate|"""
+        return float(self.lib.mvk_f32_distance_tolerance(self.ctx, float(coord_abs_max)))
+
     def collision_avoidance_batch_dev(self, d_soa, layout, d_out, damping_gain=0.01, constraint_range=0.03,
                                       forbidden_range=0.01, full_body=True, stream=None):
         """device-pointer form of collision_avoidance_batch: d_out maps any of dist [P, ld], box (int32) [P, ld],
