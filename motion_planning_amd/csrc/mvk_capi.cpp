@@ -514,7 +514,11 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
     const double margin = std::fmin(std::fmax(c->extras.reach, 0.5), 4.0);
     const double pad = 8.0 * static_cast<double>(c->f32_delta) + 4e-6 * (std::sqrt(diag) + 2.0 * margin) + 1e-6;
     GridHost gh;
-    if (build_far_grid(host.data(), n, rb, margin, pad, gh) == MVK_OK) {
+    // reach: the largest radius term any walk asks with -- the avoidance rows' group walks use grp_rq (a member off the
+    // leader's centre by o needs the boxes within radius + 2 o of the leader's nearest-box distance)
+    double far_reach = rb;
+    for (int gi = 0; gi < c->extras.n_grp; ++gi) far_reach = std::fmax(far_reach, c->extras.grp_rq[gi]);
+    if (build_far_grid(host.data(), n, far_reach, margin, pad, gh) == MVK_OK) {
       if (int rc = c->fgrid_start.reserve(sizeof(uint32_t) * gh.start.size())) return rc;
       if (int rc = c->fgrid_items.reserve(sizeof(uint16_t) * (gh.items.size() + kGridGroup))) return rc;
       HIP_TRY(hipMemcpy(c->fgrid_start.p, gh.start.data(), sizeof(uint32_t) * gh.start.size(), hipMemcpyHostToDevice));

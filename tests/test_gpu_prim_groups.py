@@ -22,6 +22,10 @@ def _workloads():
     for name, make in (("c2k", common.config2k), ("c2", common.config2), ("c3", common.config3), ("c5", common.config5)):
         w = make(n=12288)
         yield name, w.model, w.boxes, w.params, w.soa, w.layout
+    # the rim of the scenes and the space around them: the group walks then go through the far grid (whose lists must be
+    # complete for the groups' radius term, grp_rq, not only for a single primitive's) and the sweep over all boxes
+    from test_gpu_far_grid import _workloads as rim
+    yield from rim()
 
 
 def _same(x, y):
