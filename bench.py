@@ -153,7 +153,10 @@ def distance_roofline(workload, kernel, n, ms):
     k = ent.get(kernel)
     if not k:
         return None
-    insts = k["valu_insts_per_launch"] * n / (k.get("states_per_launch") or ent["states_per_launch"])
+    per = k.get("states_per_launch") or ent.get("states_per_launch")
+    if not per:
+        return {"bound": "valu_fp64", "kernel": kernel, "frac": None, "stale_pmc": "the PMC entry does not say how many states its launches held"}
+    insts = k["valu_insts_per_launch"] * n / per
     return {"bound": "valu_fp64", "kernel": kernel, "frac": insts / (ms * 1e-3) / 6.144e11,
             "frac_definition": "executed VALU wave instructions per launch (PMC SQ_INSTS_VALU) / ms / 6.144e11 per s; ms here includes "
                                "model_kernel (3-5 % of the call)" if kernel == "distance_kernel" else
@@ -574,8 +577,19 @@ def main():
         dist.broadcast(ident, 0)
         buf = (C.c_ubyte * A.COMM_ID_BYTES)(*ident.cpu().tolist())
         comm = C.c_void_p()
-        if lib.mvk_comm_create(buf, rank, world, local_rank, C.byref(comm)) != 0:
-            raise SystemExit(f"rank {rank}: mvk_comm_create: " + lib.mvk_last_error().decode())
+        rc = lib.mvk_comm_create(buf, rank, world, local_rank, C.byref(comm))
+        why = lib.mvk_last_error().decode() if rc != 0 else ""
+        # every rank must take the same path: agree on the outcome over the launcher's group, and fall back to the
+        # torch.distributed exchange (the round-2 form) everywhere if the library's communicator failed anywhere
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if rc == 0:
+                lib.mvk_comm_destroy(comm)
+            comm = None
+            args.exchange = "torch"
+            args.exchange_fallback = f"mvk_comm_create failed on some rank ({why or 'this rank was fine'}): torch.distributed exchange instead"
+            print(f"rank {rank}: {args.exchange_fallback}", file=sys.stderr)
 
     if args.workload == "c4":
         return bench_edges(args, world, rank, local_rank, dev)
@@ -790,27 +804,46 @@ def main():
                 torch.cuda.synchronize()
             out["valid_total_last_step"] = int(d_cnts[last].item())   # all-reduced over ranks (mvk_mask_count_dev + RCCL sum)
             out["exchange_by"] = "libmvk.so (mvk_gather_mask_dev -> ncclAllGather, csrc/mvk_dist.cpp)" if comm is not None else "torch.distributed"
+            if getattr(args, "exchange_fallback", None):
+                out["exchange_fallback"] = args.exchange_fallback
             out["exchange"] = ("per step: all-gather of the packed masks (RCCL); " +
                                ("on a second stream, overlapped with the next step's kernels; " if args.overlap_exchange or comm is None else "on the launch stream behind the kernels; ") +
                                ("valid count of the whole job from the gathered words every step" if args.count_every_step or comm is None else "valid count of the whole job from the gathered words after the last step"))
             out["exchange_ms"] = exchange_ms   # one exchange alone (max over ranks): what the overlap hides
             out["host_issue_ms_per_step"] = t_issued / args.steps * 1e3   # rank 0's host loop: launches + exchange calls
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(w)
-        if not args.no_planner and world == 1:
-            out["rrt_connect"] = rrt_connect_gap_pass()
-        if not args.no_edges and world == 1:
-            out["edge_checks"] = edge_checks(dev)
-        if not args.no_legs and world == 1:
-            out["workloads"] = {k: workload_leg(k, n, dev) for k in ("c2", "c3", "c5", "c5_8m", "c5_statics") if k != args.workload}
-        if not args.no_distance and world == 1 and not sweep:
-            out["distance_path"] = distance_path(eng, w, d_soa, dev, args.workload)
-        if not args.no_distance and world == 1 and not sweep:
+        def leg(name, fn):
+            # the legs beside the headline: one that fails says so in the line (and on stderr) instead of taking the
+            # headline, which is already measured, down with it
+            try:
+                out[name] = fn()
+            except Exception as e:   # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+        def single():
             eng.set_profiling(False)   # (the library's event records around each kernel would be part of every call)
-            out["single_calls"] = single_calls(eng, w)
-            eng.set_profiling(True)
+            try:
+                return single_calls(eng, w)
+            finally:
+                eng.set_profiling(True)
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
+            leg("cpu_baseline", lambda: cpu_baseline(w))
+        if not args.no_planner and world == 1:
+            leg("rrt_connect", rrt_connect_gap_pass)
+        if not args.no_edges and world == 1:
+            leg("edge_checks", lambda: edge_checks(dev))
+        if not args.no_legs and world == 1:
+            out["workloads"] = {}
+            for k in ("c2", "c3", "c5", "c5_8m", "c5_statics"):
+                if k != args.workload:
+                    leg("_wl", lambda k=k: workload_leg(k, n, dev))
+                    out["workloads"][k] = out.pop("_wl")
+        if not args.no_distance and world == 1 and not sweep:
+            leg("distance_path", lambda: distance_path(eng, w, d_soa, dev, args.workload))
+            leg("single_calls", single)
         if not args.no_fp32 and world == 1 and not sweep:
-            out["fp32_variant"] = fp32_variant(eng, w, d_soa, n, dev)
+            leg("fp32_variant", lambda: fp32_variant(eng, w, d_soa, n, dev))
         emit_line(out)
     eng.close()
     if comm is not None:

@@ -59,7 +59,7 @@ def main():
         ent = {"source": opt.get("source", os.path.basename(out.rstrip("/"))), "kernel_fingerprint": fingerprint}
         for kx in KERNELS:
             if (kx, "SQ_INSTS_VALU") in mean and (kx, "GRBM_GUI_ACTIVE") in mean and kx not in ("screen_kernel", "exact_kernel", "screen32_kernel", "fused_kernel"):
-                ent[kx] = {"valu_insts_per_launch": mean[(kx, "SQ_INSTS_VALU")], "states_per_launch": float(opt.get("states_" + kx, opt.get("states", 0)) or 0) or None,
+                ent[kx] = {"valu_insts_per_launch": mean[(kx, "SQ_INSTS_VALU")], "states_per_launch": float(opt.get("states_" + kx, opt.get("states", 0)) or 0) or mean[(kx, "SQ_WAVES")] * 64.0,  # (a lane per state)
                            "valu_busy": 4.0 * mean[(kx, "SQ_ACTIVE_INST_VALU")] / (mean[(kx, "GRBM_GUI_ACTIVE")] / 8.0 * 1024.0),
                            "wait_any_frac": mean.get((kx, "SQ_WAIT_ANY"), 0.0) / mean[(kx, "SQ_WAVE_CYCLES")] if (kx, "SQ_WAVE_CYCLES") in mean else None}
         d[opt.get("workload", "c2k") + ".distance"] = ent
