@@ -365,6 +365,45 @@ def workload_leg(name, n, dev, steps=10, warmup=2):
             "kernel_ms": [screen_ms, exact_ms]}
 
 
+def two_streams(w, d_soa, n, dev, steps=200, depth=2):
+    """Independent batches through the library's pipe (include/mvk.h mvk_pipe_*, csrc/mvk_pipe.cpp): `depth` contexts,
+    each on a stream of its own, consecutive batches handed to them round-robin.  Calls of one ctx are ordered (its
+    exact stage runs behind its screen stage and before its next call); calls of different
+    contexts are not, so the exact stage of one batch -- a latency-bound tail that keeps a twelfth of the chip busy --
+    runs beside the screen stage of the next.  Same kernels, same per-batch semantics, every batch its own mask buffer.
+    Reported beside the one-ctx headline, never as it."""
+    import torch
+
+    import motion_planning_amd as mp
+    words = (n + 63) // 64
+    ref = torch.zeros(words, dtype=torch.int64, device=dev)
+    eng = mp.Engine(w.model, w.boxes, w.params, device=dev.index)
+    eng.is_valid_mask_dev(d_soa, w.layout, ref)
+    torch.cuda.synchronize()
+    eng.close()
+    pipe = mp.Pipe(w.model, w.boxes, w.params, depth=depth, device=dev.index)
+    masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(depth)]
+    torch.cuda.synchronize()
+
+    def run(k):
+        pipe.is_valid_mask(d_soa, w.layout, masks[k % depth])
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.25:    # clocks up, as every leg
+        for k in range(16):
+            run(k)
+        pipe.drain()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        run(k)
+    pipe.drain()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    same = all(bool(torch.equal(m, ref)) for m in masks)
+    pipe.close()
+    return {"entry_point": "mvk_pipe_is_valid_mask", "contexts": depth, "streams": depth, "steps": steps, "ms_per_step": ms,
+            "checks_per_s": n / ms * 1e3, "masks_equal_one_ctx": same,
+            "note": "wall clock around the timed steps, host drained on both sides (several streams: no single stream's events bracket them)"}
+
+
 def fp32_variant(eng, w, d_soa, n, dev, steps=10):
     """BASELINE.json north_star: "fp32 variant reported with its own tolerance".  The same batch through
     MVK_PRECISION_F32_REFINED (model update, stability tests and the collision screen's frames in fp32 with error
@@ -844,6 +883,10 @@ def main():
             leg("single_calls", single)
         if not args.no_fp32 and world == 1 and not sweep:
             leg("fp32_variant", lambda: fp32_variant(eng, w, d_soa, n, dev))
+        if not args.no_legs and world == 1 and not sweep:
+            leg("two_streams", lambda: two_streams(w, d_soa, n, dev))
+            if isinstance(out.get("two_streams"), dict) and "checks_per_s" in out["two_streams"]:
+                out["value_pipelined"] = out["two_streams"]["checks_per_s"]   # (same batches through mvk_pipe, depth 2; `value` stays the one-ctx figure)
         emit_line(out)
     eng.close()
     if comm is not None:

@@ -377,6 +377,43 @@ int mvk_exchange_wait(mvk_comm* comm, int slot);
 int mvk_allreduce_stats(mvk_comm* comm, const mvk_stats* local, uint64_t index_offset, mvk_stats* global, void* stream);
 int mvk_merge_stats(const mvk_stats* locals, const uint64_t* offsets, int world, mvk_stats* global);
 
+/* ---- pipelined batches: several contexts, several streams --------------------------------------------------------
+ * No counterpart in the reference (isStateValid takes one state per call, motion_planning.cpp:76-164); part of the
+ * batched entry point the north star adds.  Calls of ONE ctx are ordered on the GPU -- the flag path's exact stage
+ * runs behind its screen stage and before the ctx's next call, since a caller may read call k's mask as soon as call k
+ * has finished on its stream -- so a stream of independent batches through one ctx leaves the chip a twelfth busy
+ * during every exact stage.  A pipe owns `depth` contexts (same model, scene and parameters), each with a stream of its
+ * own, and hands consecutive batches to them round-robin: the exact stage of batch k runs beside the screen stage of
+ * batch k + 1.  Per batch the semantics are those of the ctx entry point it calls (mvk_is_valid_mask_dev,
+ * mvk_sweep_mask_dev, mvk_eval_batch_dev): same kernels, same bits.  1 M-state batches, HYDRUS-6, 1000 boxes: 0.123 ms
+ * per batch with depth 2 against 0.140 through one ctx (bench.py, `two_streams`).
+ *   producer_stream: the stream the batch's inputs are produced on (the batch is ordered behind everything enqueued
+ *     there so far), or MVK_PIPE_NO_PRODUCER when they are ready.  NULL is the null stream, as everywhere.
+ *   ticket: names the lane the batch went to; mvk_pipe_wait(pipe, ticket, consumer_stream) orders consumer_stream
+ *     behind the lane's LATEST batch (no host wait), with MVK_PIPE_HOST it blocks the host until that batch is done.
+ *     A lane runs its batches in order, so a ticket stays good until `depth` further batches have been submitted; the
+ *     output buffers of a batch must not be handed to another batch before it has been waited for.
+ *   mvk_pipe_drain: blocks the host until every submitted batch is done.  mvk_pipe_ctx: a lane's ctx (statistics,
+ *     profiling, parameters; do not call it while the lane has work in flight on another stream).
+ * A pipe is thread-compatible like a ctx: one host thread at a time.  Memory: `depth` times a ctx's buffers. */
+typedef struct mvk_pipe mvk_pipe;
+#define MVK_PIPE_NO_PRODUCER ((void*)(intptr_t)-1)
+#define MVK_PIPE_HOST ((void*)(intptr_t)-1)
+int mvk_pipe_create(const mvk_model* model, const mvk_box* boxes, size_t n_boxes, const mvk_params* params, int device,
+                    int depth /* 1..8 */, mvk_pipe** out);
+void mvk_pipe_destroy(mvk_pipe* pipe);
+int mvk_pipe_depth(const mvk_pipe* pipe);
+mvk_ctx* mvk_pipe_ctx(mvk_pipe* pipe, int lane);
+int mvk_pipe_set_scene(mvk_pipe* pipe, const mvk_box* boxes, size_t n_boxes);   /* waits for every lane first */
+int mvk_pipe_is_valid_mask(mvk_pipe* pipe, const double* d_soa, size_t n, size_t ld, int layout, uint64_t* d_mask,
+                           void* producer_stream, int* ticket);
+int mvk_pipe_sweep_mask(mvk_pipe* pipe, const double* root_pose7, uint64_t first_index, size_t n, uint64_t seed,
+                        uint64_t* d_mask, int* ticket);
+int mvk_pipe_eval_batch(mvk_pipe* pipe, const double* d_soa, size_t n, size_t ld, int layout, uint8_t* d_flags,
+                        double* d_min_dist, double* d_margin, uint8_t* d_band, void* producer_stream, int* ticket);
+int mvk_pipe_wait(mvk_pipe* pipe, int ticket, void* consumer_stream);
+int mvk_pipe_drain(mvk_pipe* pipe);
+
 /* Full evaluation with per-sample model quantities (what MultilinkState /
  * addState expose: multilink_state.cpp:98-137, motion_planning.cpp:546-642). */
 int mvk_eval_batch(mvk_ctx* ctx, const double* soa, size_t n, size_t ld, int layout,

@@ -200,7 +200,19 @@ PROTOTYPES.update({
     "mvk_exchange_wait": (ip, [vp, ip]),
     "mvk_allreduce_stats": (ip, [vp, C.POINTER(Stats), C.c_uint64, C.POINTER(Stats), vp]),
     "mvk_merge_stats": (ip, [C.POINTER(Stats), C.POINTER(C.c_uint64), ip, C.POINTER(Stats)]),
+    # pipelined batches (csrc/mvk_pipe.cpp)
+    "mvk_pipe_create": (ip, [PM, PB, sz, PP, ip, ip, C.POINTER(vp)]),
+    "mvk_pipe_destroy": (None, [vp]),
+    "mvk_pipe_depth": (ip, [vp]),
+    "mvk_pipe_ctx": (vp, [vp, ip]),
+    "mvk_pipe_set_scene": (ip, [vp, PB, sz]),
+    "mvk_pipe_is_valid_mask": (ip, [vp, vp, sz, sz, ip, vp, vp, C.POINTER(ip)]),
+    "mvk_pipe_sweep_mask": (ip, [vp, vp, C.c_uint64, sz, C.c_uint64, vp, C.POINTER(ip)]),
+    "mvk_pipe_eval_batch": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, vp, C.POINTER(ip)]),
+    "mvk_pipe_wait": (ip, [vp, ip, vp]),
+    "mvk_pipe_drain": (ip, [vp]),
 })
+PIPE_NO_PRODUCER = C.c_void_p(-1 & (2 ** (8 * C.sizeof(C.c_void_p)) - 1))   # MVK_PIPE_NO_PRODUCER / MVK_PIPE_HOST
 COMM_ID_BYTES = 128
 
 # every symbol include/mvk_debug.h declares (diagnostics, not part of the drop-in boundary)

@@ -162,6 +162,69 @@ class Space:
         return out
 
 
+class Pipe:
+    """mvk_pipe (include/mvk.h, pipelined batches): `depth` contexts with a stream each, consecutive batches handed to
+    them round-robin so that one batch's exact stage runs beside the next batch's screen stage.  ctypes plumbing."""
+
+    def __init__(self, model, boxes, params, depth=2, device=0):
+        self.lib = A.load()
+        self.model, self.params = model, params
+        arr, n = boxes_from_array(boxes if boxes is not None else np.zeros((0, 10)))
+        self.pipe = C.c_void_p()
+        _check(self.lib, self.lib.mvk_pipe_create(C.byref(model), arr, n, C.byref(params), device, int(depth), C.byref(self.pipe)))
+        self.depth = self.lib.mvk_pipe_depth(self.pipe)
+
+    def close(self):
+        if getattr(self, "pipe", None):
+            self.lib.mvk_pipe_destroy(self.pipe)
+            self.pipe = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _producer(stream):
+        return A.PIPE_NO_PRODUCER if stream is None else C.c_void_p(stream.cuda_stream)
+
+    def set_scene(self, boxes):
+        arr, n = boxes_from_array(boxes)
+        _check(self.lib, self.lib.mvk_pipe_set_scene(self.pipe, arr, n))
+
+    def is_valid_mask(self, d_soa, layout, d_mask, producer_stream=None):
+        """submit one batch; returns its ticket.  producer_stream: torch stream the inputs are produced on (None: ready)"""
+        rows, n = d_soa.shape
+        t = C.c_int(-1)
+        _check(self.lib, self.lib.mvk_pipe_is_valid_mask(self.pipe, C.c_void_p(d_soa.data_ptr()), n, d_soa.stride(0), layout,
+                                                         C.c_void_p(d_mask.data_ptr()), self._producer(producer_stream), C.byref(t)))
+        return t.value
+
+    def sweep_mask(self, root_pose7, first_index, n, seed, d_mask):
+        pose = np.ascontiguousarray(root_pose7, np.float64)
+        t = C.c_int(-1)
+        _check(self.lib, self.lib.mvk_pipe_sweep_mask(self.pipe, _ptr(pose), int(first_index), int(n), int(seed),
+                                                      C.c_void_p(d_mask.data_ptr()), C.byref(t)))
+        return t.value
+
+    def eval_batch(self, d_soa, layout, d_flags=None, d_min_dist=None, d_margin=None, d_band=None, producer_stream=None):
+        rows, n = d_soa.shape
+        dp = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None   # noqa: E731
+        t = C.c_int(-1)
+        _check(self.lib, self.lib.mvk_pipe_eval_batch(self.pipe, C.c_void_p(d_soa.data_ptr()), n, d_soa.stride(0), layout, dp(d_flags),
+                                                      dp(d_min_dist), dp(d_margin), dp(d_band), self._producer(producer_stream), C.byref(t)))
+        return t.value
+
+    def wait(self, ticket, consumer_stream=None):
+        """consumer_stream (torch stream): ordered behind the ticket's lane on the GPU; None: block the host"""
+        _check(self.lib, self.lib.mvk_pipe_wait(self.pipe, int(ticket),
+                                                A.PIPE_NO_PRODUCER if consumer_stream is None else C.c_void_p(consumer_stream.cuda_stream)))
+
+    def drain(self):
+        _check(self.lib, self.lib.mvk_pipe_drain(self.pipe))
+
+
 class Engine:
     """Owns one mvk_ctx (one GPU).  Mirrors the role of sampling_base::MotionPlanning's
     robot_model_ptr_ + planning_scene_ for the validity path."""
