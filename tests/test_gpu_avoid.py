@@ -84,3 +84,34 @@ def test_avoidance_empty_world_and_ragged_sizes():
         part = eng.collision_avoidance_batch(st[:, :n])
         assert np.array_equal(part["dist"], full["dist"][:, :n]) and np.array_equal(part["ok"], full["ok"][:n])
     eng.close()
+
+
+@pytest.mark.parametrize("kind,n_links", [("hydrus", 6), ("dragon", 4)])
+def test_lane_per_state_kernel_in_a_swarm_of_pebbles(kind, n_links):
+    """avoid_kernel proper (more than 4096 states per call) where its fallbacks are exercised side by side: 3000 small
+    boxes put more candidates around a link than a lane's list holds (those lanes walk the whole cell, the wave's other
+    lanes take the flat drain only when no list overflowed), states above the swarm go to the far grid and the sweep."""
+    rng = np.random.default_rng(23)
+    model = mp.make_model(kind, n_links)
+    params = mp.default_params(model, A.MODE_JOINTS_AND_BASE, A.SE3)
+    J = model.n_joint
+    boxes = common.random_boxes(rng, 3000, [-1.5, -1.5, -1.5], [1.5, 1.5, 1.5], 0.02, 0.05, "so3")
+    n = 4096 + 1024
+    st = np.zeros((7 + J, n))
+    st[0:3] = rng.uniform(-1.2, 1.2, (3, n))
+    st[2, ::7] += 3.5
+    st[3:7] = common.random_unit_quats(rng, n)
+    st[7:] = rng.uniform(-1.4, 1.4, (J, n))
+    eng = mp.Engine(model, boxes, params)
+    got = eng.collision_avoidance_batch(st, A.LAYOUT_POSE7, 0.01, 0.08, 0.05, True)
+    small = eng.collision_avoidance_batch(st[:, :512], A.LAYOUT_POSE7, 0.01, 0.08, 0.05, True)     # the wave-per-state kernel
+    eng.close()
+    for key in ("dist", "box", "p_env", "p_robot", "row", "lb", "ok"):
+        a, b = got[key][..., :512], small[key]
+        assert np.array_equal(a, b, equal_nan=True), key
+    idx = np.linspace(0, n - 1, 500).astype(int)
+    ref = O.avoid_batch(model, boxes, params, np.ascontiguousarray(st[:, idx]), 0.01, 0.08, 0.05, True)
+    assert np.array_equal(got["ok"][idx], ref["ok"])
+    assert np.allclose(got["dist"][:, idx], ref["dist"], rtol=1e-5, atol=1e-9)
+    assert (got["box"][:, idx] == ref["box"]).mean() > 0.999
+    assert (ref["dist"] < 0).mean() > 0.02 and (ref["dist"] > 0.5).mean() > 0.02
