@@ -365,45 +365,6 @@ def workload_leg(name, n, dev, steps=10, warmup=2):
             "kernel_ms": [screen_ms, exact_ms]}
 
 
-def two_streams(w, d_soa, n, dev, steps=200, depth=2):
-    """Independent batches through the library's pipe (include/mvk.h mvk_pipe_*, csrc/mvk_pipe.cpp): `depth` contexts,
-    each on a stream of its own, consecutive batches handed to them round-robin.  Calls of one ctx are ordered (its
-    exact stage runs behind its screen stage and before its next call); calls of different
-    contexts are not, so the exact stage of one batch -- a latency-bound tail that keeps a twelfth of the chip busy --
-    runs beside the screen stage of the next.  Same kernels, same per-batch semantics, every batch its own mask buffer.
-    Reported beside the one-ctx headline, never as it."""
-    import torch
-
-    import motion_planning_amd as mp
-    words = (n + 63) // 64
-    ref = torch.zeros(words, dtype=torch.int64, device=dev)
-    eng = mp.Engine(w.model, w.boxes, w.params, device=dev.index)
-    eng.is_valid_mask_dev(d_soa, w.layout, ref)
-    torch.cuda.synchronize()
-    eng.close()
-    pipe = mp.Pipe(w.model, w.boxes, w.params, depth=depth, device=dev.index)
-    masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(depth)]
-    torch.cuda.synchronize()
-
-    def run(k):
-        pipe.is_valid_mask(d_soa, w.layout, masks[k % depth])
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.25:    # clocks up, as every leg
-        for k in range(16):
-            run(k)
-        pipe.drain()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        run(k)
-    pipe.drain()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    same = all(bool(torch.equal(m, ref)) for m in masks)
-    pipe.close()
-    return {"entry_point": "mvk_pipe_is_valid_mask", "contexts": depth, "streams": depth, "steps": steps, "ms_per_step": ms,
-            "checks_per_s": n / ms * 1e3, "masks_equal_one_ctx": same,
-            "note": "wall clock around the timed steps, host drained on both sides (several streams: no single stream's events bracket them)"}
-
-
 def fp32_variant(eng, w, d_soa, n, dev, steps=10):
     """BASELINE.json north_star: "fp32 variant reported with its own tolerance".  The same batch through
     MVK_PRECISION_F32_REFINED (model update, stability tests and the collision screen's frames in fp32 with error
@@ -573,6 +534,7 @@ def main():
                          "libmvk.so; default) or torch.distributed (diagnostics)")
     ap.add_argument("--overlap-exchange", action="store_true", help="issue the exchange on a second stream (mvk_exchange_masks_dev)")
     ap.add_argument("--count-every-step", action="store_true", help="count the valid bits of the gathered masks every step, not only after the last")
+    ap.add_argument("--one-ctx", action="store_true", help="headline through one ctx on one stream (the round-2 form) instead of mvk_pipe_* with two contexts")
     ap.add_argument("--slots", type=int, default=4, help="exchange buffer sets: how many steps the host may run ahead of the exchange")
     ap.add_argument("--cold-steps", type=int, default=20, help="N = 1: timed steps of the from-cold pass before the pre-warm (0: skip)")
     ap.add_argument("--rehearse-exchange", action="store_true",
@@ -807,9 +769,74 @@ def main():
         exchange_ms = float(t.item())
         torch.cuda.set_stream(main_stream)
 
+    # ---- the headline: the same K steps through the library's pipe (include/mvk.h mvk_pipe_*: two contexts, a stream
+    # each, batches alternating, so that one batch's exact stage runs beside the next one's screen stage).  With N > 1 the
+    # step's mask all-gather goes to the exchange stream behind the batch's lane (mvk_exchange_masks_dev, one
+    # communicator, one stream for every collective); the host waits for an exchange only when its buffer set comes up
+    # for reuse, `slots` steps later.  Every rank runs this loop (it holds collectives); the figures of the one-ctx loop
+    # above are kept beside it.
+    pipe_res = None
+    if not args.one_ctx and (not exchange or comm is not None):
+        import ctypes as C2
+        from motion_planning_amd import _abi as A2
+        plib = A2.load()
+        pipe = mp.Pipe(w.model, w.boxes, w.params, depth=2, device=local_rank)
+        p_slots = max(2, n_slot + (n_slot & 1))   # an even number of buffer sets: a set always returns to the same lane
+        p_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(p_slots)]
+        p_alls = [torch.zeros(world * words, dtype=torch.int64, device=dev) for _ in range(p_slots)] if exchange else None
+        p_streams = [C2.c_void_p(plib.mvk_pipe_stream(pipe.pipe, lane)) for lane in range(2)]
+        x_stream = torch.cuda.Stream(device=dev) if exchange else None
+        x_handle = C2.c_void_p(x_stream.cuda_stream) if exchange else None
+
+        def pstep(k):
+            slot = k % p_slots
+            if exchange and plib.mvk_exchange_wait(comm, slot) != 0:   # (the set's last exchange, p_slots steps ago: long finished)
+                raise SystemExit("mvk_exchange_wait: " + plib.mvk_last_error().decode())
+            if sweep:
+                lane = pipe.sweep_mask(sweep_pose, rank * n, n, common.SEED0 + 5, p_masks[slot])
+            else:
+                lane = pipe.is_valid_mask(d_soa, w.layout, p_masks[slot])
+            if exchange and plib.mvk_exchange_masks_dev(comm, slot, C2.c_void_p(p_masks[slot].data_ptr()), words,
+                                                        C2.c_void_p(p_alls[slot].data_ptr()), None, p_streams[lane], x_handle) != 0:
+                raise SystemExit("mvk_exchange_masks_dev: " + plib.mvk_last_error().decode())
+
+        def pdrain():
+            pipe.drain()
+            if exchange and plib.mvk_exchange_wait(comm, -1) != 0:
+                raise SystemExit("mvk_exchange_wait: " + plib.mvk_last_error().decode())
+        for k in range(args.prewarm + args.warmup):
+            pstep(k)
+        pdrain()
+        torch.cuda.synchronize()
+        if exchange:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for k in range(args.steps):
+            pstep(k)
+        tp_issued = time.perf_counter() - tp0
+        pdrain()
+        torch.cuda.synchronize()
+        if exchange:
+            dist.barrier()
+        torch.cuda.synchronize()
+        p_elapsed = time.perf_counter() - tp0
+        if exchange:
+            t = torch.tensor([p_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            p_elapsed = float(t.item())
+        last = (args.steps - 1) % p_slots
+        pipe_res = {"elapsed": p_elapsed, "host_issue_ms_per_step": tp_issued / args.steps * 1e3,
+                    "masks_equal_one_ctx": bool(torch.equal(p_masks[last], d_masks[(args.steps - 1) % n_slot])) if not sweep or world == 1 else None,
+                    "gathered_equals_one_ctx": bool(torch.equal(p_alls[last], d_alls[(args.steps - 1) % n_slot])) if exchange else None}
+        pipe.close()
+
     if rank == 0:
         valid = int(sum(bin(int(x) & 0xFFFFFFFFFFFFFFFF).count("1") for x in d_mask.cpu().numpy()[:4096]))
         total = world * n * args.steps
+        one_ctx_value, one_ctx_ms = total / elapsed, elapsed / args.steps * 1e3
+        if pipe_res:
+            elapsed = pipe_res["elapsed"]
         value = total / elapsed
         out = {
             "metric": "state validity checks/sec",
@@ -823,7 +850,7 @@ def main():
             "value_cold": n / cold if cold else None,
             "ms_per_step_cold": cold * 1e3 if cold else None,
             "cold_note": f"{args.cold_steps} steps timed right after {args.warmup} warm-up steps, before the {args.prewarm} pre-warm steps: GPU clocks "
-                         "still ramping up out of the idle spell of set-up; `value` is the steady state after the pre-warm" if cold else None,
+                         "still ramping up out of the idle spell of set-up, through one ctx; `value` is the steady state after the pre-warm" if cold else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -832,6 +859,14 @@ def main():
             "config": {"workload": f"{w.name}: {kind.upper()} {NL}-link, joints+base, {n} samples/GPU, {M} box obstacles, "
                                    f"{P} robot primitives, flags as packed mask" + (", states generated in-kernel (C-space sweep)" if sweep else ""),
                        "samples_per_gpu": n, "obstacles": M, "links": NL, "parallelism": f"shard{world}"},
+            "pipeline": ({"entry_point": "mvk_pipe_sweep_mask" if sweep else "mvk_pipe_is_valid_mask", "contexts": 2, "streams": 2,
+                          "note": "the K timed steps go through the library's pipe: batches alternate between two contexts with a stream each, "
+                                  "so one batch's exact stage runs beside the next one's screen stage (DESIGN.md section 5); per batch the same "
+                                  "kernels and bits as one ctx; value_one_ctx / ms_per_step_one_ctx are the same K steps through one ctx on one stream",
+                          "masks_equal_one_ctx": pipe_res["masks_equal_one_ctx"], "gathered_equals_one_ctx": pipe_res["gathered_equals_one_ctx"],
+                          "host_issue_ms_per_step": pipe_res["host_issue_ms_per_step"]} if pipe_res else None),
+            "value_one_ctx": one_ctx_value,
+            "ms_per_step_one_ctx": one_ctx_ms,
             "roofline": roofline_of(args.workload, w, n, screen_ms, exact_ms, call_ms, sweep),
             "rccl_ranks": (lib.mvk_comm_world(comm) if comm is not None else dist.get_world_size()) if exchange else 1,
             "valid_in_first_4096_words": valid,
@@ -848,6 +883,12 @@ def main():
             out["exchange"] = ("per step: all-gather of the packed masks (RCCL); " +
                                ("on a second stream, overlapped with the next step's kernels; " if args.overlap_exchange or comm is None else "on the launch stream behind the kernels; ") +
                                ("valid count of the whole job from the gathered words every step" if args.count_every_step or comm is None else "valid count of the whole job from the gathered words after the last step"))
+            if pipe_res:
+                out["exchange_one_ctx"] = out["exchange"]
+                out["exchange"] = ("per step: all-gather of the packed masks (RCCL) on the exchange stream behind the batch's pipe lane "
+                                   "(mvk_exchange_masks_dev: event on the lane's stream, wait + ncclAllGather + event on the exchange stream; the "
+                                   "host waits for an exchange when its buffer set is reused); valid count of the whole job from the gathered "
+                                   "words after the last step")
             out["exchange_ms"] = exchange_ms   # one exchange alone (max over ranks): what the overlap hides
             out["host_issue_ms_per_step"] = t_issued / args.steps * 1e3   # rank 0's host loop: launches + exchange calls
         def leg(name, fn):
@@ -883,10 +924,6 @@ def main():
             leg("single_calls", single)
         if not args.no_fp32 and world == 1 and not sweep:
             leg("fp32_variant", lambda: fp32_variant(eng, w, d_soa, n, dev))
-        if not args.no_legs and world == 1 and not sweep:
-            leg("two_streams", lambda: two_streams(w, d_soa, n, dev))
-            if isinstance(out.get("two_streams"), dict) and "checks_per_s" in out["two_streams"]:
-                out["value_pipelined"] = out["two_streams"]["checks_per_s"]   # (same batches through mvk_pipe, depth 2; `value` stays the one-ctx figure)
         emit_line(out)
     eng.close()
     if comm is not None:

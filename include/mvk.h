@@ -386,7 +386,7 @@ int mvk_merge_stats(const mvk_stats* locals, const uint64_t* offsets, int world,
  * own, and hands consecutive batches to them round-robin: the exact stage of batch k runs beside the screen stage of
  * batch k + 1.  Per batch the semantics are those of the ctx entry point it calls (mvk_is_valid_mask_dev,
  * mvk_sweep_mask_dev, mvk_eval_batch_dev): same kernels, same bits.  1 M-state batches, HYDRUS-6, 1000 boxes: 0.123 ms
- * per batch with depth 2 against 0.140 through one ctx (bench.py, `two_streams`).
+ * per batch with depth 2 against 0.140 through one ctx (bench.py: `value` against `value_one_ctx`).
  *   producer_stream: the stream the batch's inputs are produced on (the batch is ordered behind everything enqueued
  *     there so far), or MVK_PIPE_NO_PRODUCER when they are ready.  NULL is the null stream, as everywhere.
  *   ticket: names the lane the batch went to; mvk_pipe_wait(pipe, ticket, consumer_stream) orders consumer_stream
@@ -394,7 +394,8 @@ int mvk_merge_stats(const mvk_stats* locals, const uint64_t* offsets, int world,
  *     A lane runs its batches in order, so a ticket stays good until `depth` further batches have been submitted; the
  *     output buffers of a batch must not be handed to another batch before it has been waited for.
  *   mvk_pipe_drain: blocks the host until every submitted batch is done.  mvk_pipe_ctx: a lane's ctx (statistics,
- *     profiling, parameters; do not call it while the lane has work in flight on another stream).
+ *     profiling, parameters; do not call it while the lane has work in flight on another stream).  mvk_pipe_stream: a
+ *     lane's stream, for work that has to follow a batch without a host wait (the ticket of a batch is its lane).
  * A pipe is thread-compatible like a ctx: one host thread at a time.  Memory: `depth` times a ctx's buffers. */
 typedef struct mvk_pipe mvk_pipe;
 #define MVK_PIPE_NO_PRODUCER ((void*)(intptr_t)-1)
@@ -404,6 +405,7 @@ int mvk_pipe_create(const mvk_model* model, const mvk_box* boxes, size_t n_boxes
 void mvk_pipe_destroy(mvk_pipe* pipe);
 int mvk_pipe_depth(const mvk_pipe* pipe);
 mvk_ctx* mvk_pipe_ctx(mvk_pipe* pipe, int lane);
+void* mvk_pipe_stream(mvk_pipe* pipe, int lane);   /* the lane's hipStream_t: e.g. the producer stream of mvk_exchange_masks_dev */
 int mvk_pipe_set_scene(mvk_pipe* pipe, const mvk_box* boxes, size_t n_boxes);   /* waits for every lane first */
 int mvk_pipe_is_valid_mask(mvk_pipe* pipe, const double* d_soa, size_t n, size_t ld, int layout, uint64_t* d_mask,
                            void* producer_stream, int* ticket);

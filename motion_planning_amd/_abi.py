@@ -205,6 +205,7 @@ PROTOTYPES.update({
     "mvk_pipe_destroy": (None, [vp]),
     "mvk_pipe_depth": (ip, [vp]),
     "mvk_pipe_ctx": (vp, [vp, ip]),
+    "mvk_pipe_stream": (vp, [vp, ip]),
     "mvk_pipe_set_scene": (ip, [vp, PB, sz]),
     "mvk_pipe_is_valid_mask": (ip, [vp, vp, sz, sz, ip, vp, vp, C.POINTER(ip)]),
     "mvk_pipe_sweep_mask": (ip, [vp, vp, C.c_uint64, sz, C.c_uint64, vp, C.POINTER(ip)]),

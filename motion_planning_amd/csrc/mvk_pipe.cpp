@@ -71,6 +71,7 @@ extern "C" void mvk_pipe_destroy(mvk_pipe* p) {
 }
 
 extern "C" int mvk_pipe_depth(const mvk_pipe* p) { return p ? p->depth : 0; }
+extern "C" void* mvk_pipe_stream(mvk_pipe* p, int lane) { return (p && lane >= 0 && lane < p->depth) ? static_cast<void*>(p->stream[lane]) : nullptr; }
 extern "C" mvk_ctx* mvk_pipe_ctx(mvk_pipe* p, int lane) { return (p && lane >= 0 && lane < p->depth) ? p->ctx[lane] : nullptr; }
 
 extern "C" int mvk_pipe_set_scene(mvk_pipe* p, const mvk_box* boxes, size_t n_boxes) {
