@@ -75,6 +75,13 @@ def test_no_device_means_loud_failure_not_fallback():
     with pytest.raises(mp.MvkError) as e:
         mp.Engine(m, np.zeros((0, 10)), p)
     assert "no HIP device" in str(e.value) or "not gfx950" in str(e.value)
+    with pytest.raises(mp.MvkError) as e:          # the pipe owns contexts: the same refusal, nothing half-built
+        mp.Pipe(m, np.zeros((0, 10)), p, depth=2)
+    assert "no HIP device" in str(e.value) or "not gfx950" in str(e.value)
+    with pytest.raises(mp.MvkError):
+        mp.Pipe(m, np.zeros((0, 10)), p, depth=0)
+    assert lib.mvk_pipe_depth(None) == 0 and not lib.mvk_pipe_ctx(None, 0) and not lib.mvk_pipe_stream(None, 0)
+    lib.mvk_pipe_destroy(None)
 
 
 def test_gap_worlds_literal_numbers():
