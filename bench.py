@@ -356,8 +356,32 @@ def workload_leg(name, n, dev, steps=10, warmup=2):
     screen_ms, exact_ms = float(np.mean([x[0] for x in split])), float(np.mean([x[1] for x in split]))
     bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")[:n]
     eng.close()
+    # the same batches through the library's pipe (two contexts, two streams), as the headline's timed steps
+    pipe = mp.Pipe(w.model, w.boxes, w.params, depth=2, device=dev.index)
+    pmasks = [torch.zeros_like(mask) for _ in range(2)]
+
+    def prun(k):
+        if sweep:
+            pipe.sweep_mask(pose, 0, n, common.SEED0 + 5, pmasks[k & 1])
+        else:
+            pipe.is_valid_mask(d_soa, w.layout, pmasks[k & 1])
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.25:
+        for k in range(16):
+            prun(k)
+        pipe.drain()
+    t0 = time.perf_counter()
+    psteps = 200   # (wall clock with a drain on both sides: enough steps for the ends not to count)
+    for k in range(psteps):
+        prun(k)
+    pipe.drain()
+    pms = (time.perf_counter() - t0) / psteps * 1e3
+    psame = bool(torch.equal(pmasks[0], mask) and torch.equal(pmasks[1], mask))
+    pipe.close()
     kind = "dragon" if w.model.has_gimbal else "hydrus"
-    return {"workload": f"{name}: {kind.upper()} {w.model.n_rotor}-link, {n} samples, {len(w.boxes)} box obstacles"
+    return {"pipelined": {"entry_point": "mvk_pipe_sweep_mask" if sweep else "mvk_pipe_is_valid_mask", "ms_per_step": pms, "checks_per_s": n / pms * 1e3,
+                          "steps": psteps, "masks_equal_one_ctx": psame},
+            "workload": f"{name}: {kind.upper()} {w.model.n_rotor}-link, {n} samples, {len(w.boxes)} box obstacles"
                         + (", states generated in-kernel (C-space sweep)" if sweep else "")
                         + (", planning mode 0: joints only, stability verdict alone" if statics_only else ""),
             "ms_per_step": ms, "checks_per_s": n / ms * 1e3, "steps": steps, "valid_fraction": float(bits.mean()),
