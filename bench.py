@@ -586,35 +586,46 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    comm = None
+    comm, comm_b = None, None
     if exchange and args.exchange == "mvk":
-        # the library's own communicator (csrc/mvk_dist.cpp: ncclCommInitRank from libmvk.so); the 128-byte id travels
-        # over the process group the launcher set up, which also serves the barrier and the max-over-ranks below
+        # the library's own communicators (csrc/mvk_dist.cpp: ncclCommInitRank from libmvk.so); a 128-byte id travels
+        # over the process group the launcher set up, which also serves the barrier and the max-over-ranks below.  Two of
+        # them: the pipelined loop issues the all-gather of a batch on the stream of the pipe lane that ran it, and a
+        # communicator takes its collectives from one stream at a time -- one communicator per lane.
         import ctypes as C
         from motion_planning_amd import _abi as A
         lib = A.load()
-        ident = torch.zeros(A.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            buf = (C.c_ubyte * A.COMM_ID_BYTES)()
-            if lib.mvk_comm_unique_id(buf) != 0:
-                raise SystemExit("mvk_comm_unique_id: " + lib.mvk_last_error().decode())
-            ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
-        dist.broadcast(ident, 0)
-        buf = (C.c_ubyte * A.COMM_ID_BYTES)(*ident.cpu().tolist())
-        comm = C.c_void_p()
-        rc = lib.mvk_comm_create(buf, rank, world, local_rank, C.byref(comm))
-        why = lib.mvk_last_error().decode() if rc != 0 else ""
-        # every rank must take the same path: agree on the outcome over the launcher's group, and fall back to the
-        # torch.distributed exchange (the round-2 form) everywhere if the library's communicator failed anywhere
-        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            if rc == 0:
-                lib.mvk_comm_destroy(comm)
-            comm = None
+
+        def make_comm():
+            ident = torch.zeros(A.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                buf = (C.c_ubyte * A.COMM_ID_BYTES)()
+                if lib.mvk_comm_unique_id(buf) != 0:
+                    raise SystemExit("mvk_comm_unique_id: " + lib.mvk_last_error().decode())
+                ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+            dist.broadcast(ident, 0)
+            buf = (C.c_ubyte * A.COMM_ID_BYTES)(*ident.cpu().tolist())
+            c = C.c_void_p()
+            rc = lib.mvk_comm_create(buf, rank, world, local_rank, C.byref(c))
+            why = lib.mvk_last_error().decode() if rc != 0 else ""
+            # every rank must take the same path: agree on the outcome over the launcher's group
+            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if rc == 0:
+                    lib.mvk_comm_destroy(c)
+                return None, why or "this rank was fine"
+            return c, ""
+        comm, why = make_comm()
+        if comm is None:   # fall back to the torch.distributed exchange (the round-2 form) everywhere
             args.exchange = "torch"
-            args.exchange_fallback = f"mvk_comm_create failed on some rank ({why or 'this rank was fine'}): torch.distributed exchange instead"
+            args.exchange_fallback = f"mvk_comm_create failed on some rank ({why}): torch.distributed exchange instead"
             print(f"rank {rank}: {args.exchange_fallback}", file=sys.stderr)
+        elif not args.one_ctx:
+            comm_b, why = make_comm()
+            if comm_b is None:
+                args.exchange_fallback = f"second communicator failed on some rank ({why}): headline through one ctx"
+                print(f"rank {rank}: {args.exchange_fallback}", file=sys.stderr)
 
     if args.workload == "c4":
         return bench_edges(args, world, rank, local_rank, dev)
@@ -795,12 +806,11 @@ def main():
 
     # ---- the headline: the same K steps through the library's pipe (include/mvk.h mvk_pipe_*: two contexts, a stream
     # each, batches alternating, so that one batch's exact stage runs beside the next one's screen stage).  With N > 1 the
-    # step's mask all-gather goes to the exchange stream behind the batch's lane (mvk_exchange_masks_dev, one
-    # communicator, one stream for every collective); the host waits for an exchange only when its buffer set comes up
-    # for reuse, `slots` steps later.  Every rank runs this loop (it holds collectives); the figures of the one-ctx loop
-    # above are kept beside it.
+    # step's mask all-gather follows the batch on its lane's own stream (mvk_gather_mask_dev with mvk_pipe_stream(lane),
+    # one communicator per lane): the other lane's kernels run beside it, no event crosses streams, the host never
+    # waits.  Every rank runs this loop (it holds collectives); the figures of the one-ctx loop above are kept beside it.
     pipe_res = None
-    if not args.one_ctx and (not exchange or comm is not None):
+    if not args.one_ctx and (not exchange or (comm is not None and comm_b is not None)):
         import ctypes as C2
         from motion_planning_amd import _abi as A2
         plib = A2.load()
@@ -809,25 +819,22 @@ def main():
         p_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(p_slots)]
         p_alls = [torch.zeros(world * words, dtype=torch.int64, device=dev) for _ in range(p_slots)] if exchange else None
         p_streams = [C2.c_void_p(plib.mvk_pipe_stream(pipe.pipe, lane)) for lane in range(2)]
-        x_stream = torch.cuda.Stream(device=dev) if exchange else None
-        x_handle = C2.c_void_p(x_stream.cuda_stream) if exchange else None
+        p_comms = [comm, comm_b]
 
         def pstep(k):
+            # a buffer set always returns to the same lane (p_slots is even), and a lane runs its work in order: the
+            # all-gather of step k has left the set's mask long before step k + p_slots writes it -- no event, no host wait
             slot = k % p_slots
-            if exchange and plib.mvk_exchange_wait(comm, slot) != 0:   # (the set's last exchange, p_slots steps ago: long finished)
-                raise SystemExit("mvk_exchange_wait: " + plib.mvk_last_error().decode())
             if sweep:
                 lane = pipe.sweep_mask(sweep_pose, rank * n, n, common.SEED0 + 5, p_masks[slot])
             else:
                 lane = pipe.is_valid_mask(d_soa, w.layout, p_masks[slot])
-            if exchange and plib.mvk_exchange_masks_dev(comm, slot, C2.c_void_p(p_masks[slot].data_ptr()), words,
-                                                        C2.c_void_p(p_alls[slot].data_ptr()), None, p_streams[lane], x_handle) != 0:
-                raise SystemExit("mvk_exchange_masks_dev: " + plib.mvk_last_error().decode())
+            if exchange and plib.mvk_gather_mask_dev(p_comms[lane], C2.c_void_p(p_masks[slot].data_ptr()), words,
+                                                     C2.c_void_p(p_alls[slot].data_ptr()), p_streams[lane]) != 0:
+                raise SystemExit("mvk_gather_mask_dev: " + plib.mvk_last_error().decode())
 
         def pdrain():
             pipe.drain()
-            if exchange and plib.mvk_exchange_wait(comm, -1) != 0:
-                raise SystemExit("mvk_exchange_wait: " + plib.mvk_last_error().decode())
         for k in range(args.prewarm + args.warmup):
             pstep(k)
         pdrain()
@@ -909,10 +916,9 @@ def main():
                                ("valid count of the whole job from the gathered words every step" if args.count_every_step or comm is None else "valid count of the whole job from the gathered words after the last step"))
             if pipe_res:
                 out["exchange_one_ctx"] = out["exchange"]
-                out["exchange"] = ("per step: all-gather of the packed masks (RCCL) on the exchange stream behind the batch's pipe lane "
-                                   "(mvk_exchange_masks_dev: event on the lane's stream, wait + ncclAllGather + event on the exchange stream; the "
-                                   "host waits for an exchange when its buffer set is reused); valid count of the whole job from the gathered "
-                                   "words after the last step")
+                out["exchange"] = ("per step: all-gather of the packed masks (RCCL) behind the batch on its pipe lane's own stream "
+                                   "(mvk_gather_mask_dev, one communicator per lane; the other lane's kernels run beside it); valid count of "
+                                   "the whole job from the gathered words after the last step")
             out["exchange_ms"] = exchange_ms   # one exchange alone (max over ranks): what the overlap hides
             out["host_issue_ms_per_step"] = t_issued / args.steps * 1e3   # rank 0's host loop: launches + exchange calls
         def leg(name, fn):
@@ -950,6 +956,8 @@ def main():
             leg("fp32_variant", lambda: fp32_variant(eng, w, d_soa, n, dev))
         emit_line(out)
     eng.close()
+    if comm_b is not None:
+        lib.mvk_comm_destroy(comm_b)
     if comm is not None:
         lib.mvk_comm_destroy(comm)
     if exchange:
