@@ -42,8 +42,8 @@ extern "C" int mvk_pipe_create(const mvk_model* model, const mvk_box* boxes, siz
   // The lanes are only worth having if their streams reach the GPU through DIFFERENT hardware queues (HIP has a handful
   // per process and hands them to streams as they are created; after a few create / destroy cycles two fresh streams can
   // end up behind one queue, and the lanes then run one after the other: measured, 0.120 -> 0.144 ms per batch).  The
-  // runtime keeps a separate set of queues per stream priority, so the lanes take different priorities; which lane is
-  // "high" does not matter, the batches alternate.
+  // runtime keeps a separate set of queues per stream priority, so the lanes take different priorities, from the lowest
+  // up (depth 2: low and normal); which lane has which does not matter, the batches alternate.
   int prio_least = 0, prio_greatest = 0;
   for (int i = 0; i < depth; ++i) {
     p->ctx[i] = mvk_create(model, boxes, n_boxes, params, device);  // (sets the device; its own error text on failure)
@@ -51,7 +51,7 @@ extern "C" int mvk_pipe_create(const mvk_model* model, const mvk_box* boxes, siz
     p->depth = i + 1;
     if (i == 0 && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
     const int levels = prio_least - prio_greatest + 1;  // (numerically, the greatest priority is the smallest value)
-    const int prio = prio_greatest + (levels > 1 ? i % levels : 0);
+    const int prio = prio_least - (levels > 1 ? i % levels : 0);  // from the lowest up: never above the caller's own streams
     if (hipStreamCreateWithPriority(&p->stream[i], hipStreamNonBlocking, prio) != hipSuccess ||
         hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming) != hipSuccess) {
       mvk_pipe_destroy(p);
