@@ -121,3 +121,50 @@ def test_communicator_of_one_rank_over_rccl():
     # argument errors do not reach RCCL
     assert lib.mvk_comm_create(ident, 1, 1, 0, C.byref(comm)) == A.ERR_INVALID_ARG
     assert lib.mvk_comm_create(ident, 0, 1, 99, C.byref(comm)) == A.ERR_NO_DEVICE
+
+
+@pytest.mark.gpu
+def test_a_communicator_per_pipe_lane_gathers_on_the_lanes_streams():
+    """bench.py --gpus N: every rank runs a pipe (include/mvk.h mvk_pipe_*), a batch's all-gather follows it on its lane's
+    own stream through the lane's own communicator -- two communicators alive side by side, collectives of either issued
+    while the other lane computes.  With one rank the gathered words are the lane's mask; eight batches, in order."""
+    import torch
+    lib = A.load()
+    dev = torch.device("cuda", 0)
+    comms = []
+    for _ in range(2):
+        ident = (C.c_ubyte * A.COMM_ID_BYTES)()
+        assert lib.mvk_comm_unique_id(ident) == 0, lib.mvk_last_error()
+        c = C.c_void_p()
+        assert lib.mvk_comm_create(ident, 0, 1, 0, C.byref(c)) == 0, lib.mvk_last_error()
+        comms.append(c)
+    try:
+        n = 1 << 16
+        w = common.config2k(n=n)
+        words = n // 64
+        rng = np.random.default_rng(9)
+        batches = [torch.from_numpy(np.ascontiguousarray(w.soa[:, rng.permutation(n)])).to(dev) for _ in range(8)]
+        eng = mp.Engine(w.model, w.boxes, w.params)
+        want = []
+        for b in batches:
+            m = torch.zeros(words, dtype=torch.int64, device=dev)
+            eng.is_valid_mask_dev(b, w.layout, m)
+            torch.cuda.synchronize()
+            want.append(m.clone())
+        eng.close()
+        pipe = mp.Pipe(w.model, w.boxes, w.params, depth=2)
+        streams = [C.c_void_p(lib.mvk_pipe_stream(pipe.pipe, lane)) for lane in range(2)]
+        assert streams[0].value and streams[1].value and streams[0].value != streams[1].value
+        masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(4)]     # four buffer sets, reused
+        alls = [torch.full((words,), -1, dtype=torch.int64, device=dev) for _ in range(8)]
+        for k, b in enumerate(batches):
+            lane = pipe.is_valid_mask(b, w.layout, masks[k % 4])
+            assert lane == k % 2
+            assert lib.mvk_gather_mask_dev(comms[lane], masks[k % 4].data_ptr(), words, alls[k].data_ptr(), streams[lane]) == 0, lib.mvk_last_error()
+        pipe.drain()
+        for k in range(8):
+            assert torch.equal(alls[k], want[k]), k
+        pipe.close()
+    finally:
+        for c in comms:
+            assert lib.mvk_comm_destroy(c) == 0
