@@ -107,7 +107,24 @@ int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_
           }
     };
     std::vector<uint32_t> count(ncell, 0u);
-    for (size_t i = 0; i < n; ++i) for_cells(i, [&](uint64_t c, double) { ++count[c]; });
+    // the (cell, bound) hits of the counting pass are kept and replayed by the filling pass (the bound against a cell is
+    // the costly part of either); beyond kHitKeep hits the filling pass computes them again
+    struct Hit { uint32_t cell; float lb; };
+    constexpr size_t kHitKeep = size_t{1} << 24;
+    std::vector<Hit> hits;
+    std::vector<uint32_t> hits_of_box(n + 1, 0u);
+    bool kept = true;
+    for (size_t i = 0; i < n; ++i) {
+      hits_of_box[i] = static_cast<uint32_t>(hits.size());
+      for_cells(i, [&](uint64_t c, double lb) {
+        ++count[c];
+        if (kept) {
+          if (hits.size() < kHitKeep) hits.push_back(Hit{static_cast<uint32_t>(c), static_cast<float>(lb)});
+          else kept = false;
+        }
+      });
+    }
+    hits_of_box[n] = static_cast<uint32_t>(hits.size());
     uint64_t groups = 0;
     for (uint64_t c = 0; c < ncell; ++c) groups += (count[c] + kGridGroup - 1) / kGridGroup;
     if (groups * kGridGroup > kGridMaxItems) continue;
@@ -122,14 +139,18 @@ int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_
     std::fill(count.begin(), count.end(), 0u);
     std::vector<float> lbs;
     if (by_bound) lbs.assign(g.items.size(), INFINITY);
-    for (size_t i = 0; i < n; ++i)  // boxes in ascending id order inside every cell
-      for_cells(i, [&](uint64_t c, double lb) {
-        const size_t at_item = static_cast<size_t>(g.start[c]) * kGridGroup + count[c]++;
-        g.items[at_item] = static_cast<uint16_t>(i);
-        // (the cube test above took the cell with hh exact; the device may file a point within 1e-7 of a face under
-        // the neighbouring cell: the bound gives that much away, and the caller's pad)
-        if (by_bound) lbs[at_item] = static_cast<float>(std::max(0.0, lb * (1.0 - 1e-6) - pad - 1e-6));
-      });
+    auto place = [&](size_t i, uint64_t c, double lb) {
+      const size_t at_item = static_cast<size_t>(g.start[c]) * kGridGroup + count[c]++;
+      g.items[at_item] = static_cast<uint16_t>(i);
+      // (the cube test above took the cell with hh exact; the device may file a point within 1e-7 of a face under
+      // the neighbouring cell: the bound gives that much away, and the caller's pad; the float of a kept hit may sit
+      // half an ulp above the double it came from: the relative 1e-6 covers that as well)
+      if (by_bound) lbs[at_item] = static_cast<float>(std::max(0.0, lb * (1.0 - 1e-6) - pad - 1e-6));
+    };
+    for (size_t i = 0; i < n; ++i) {  // boxes in ascending id order inside every cell
+      if (kept) for (uint32_t e = hits_of_box[i]; e < hits_of_box[i + 1]; ++e) place(i, hits[e].cell, static_cast<double>(hits[e].lb));
+      else for_cells(i, [&](uint64_t c, double lb) { place(i, c, lb); });
+    }
     if (by_bound) {  // ... then by bound, ascending (ties: by id), the padding last
       g.glb.assign(at, 0.0f);
       std::vector<std::pair<float, uint16_t>> cell;
