@@ -29,10 +29,20 @@ def main():
     fp_file = os.path.join(out, "kernel_fingerprint.txt")
     fingerprint = open(fp_file).read().strip() if os.path.exists(fp_file) else None
     print(f"== kernel source fingerprint at collection time: {fingerprint} (profiles/fingerprint.py) ==")
-    print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+    both = os.path.isdir(os.path.join(out, "trace_pipe"))
+    print("== kernel stats (rocprofv3 --kernel-trace --stats" + (" -- python3 bench.py ... --one-ctx: launches back to back on one stream; "
+          "the launch duration roofline.achieved is priced on, bench.py's roofline.kernel_ms)" if both else ")") + " ==")
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+    if both:
+        print("== kernel stats of the default command (its pre-warm and timed steps run through one ctx AND through the pipe; in the pipe two "
+              "contexts' kernels share the chip, so a kernel's duration there includes the time it shares: not a launch duration to price "
+              "a roofline on -- the pipe's figure is ms_per_step) ==")
+        for f in glob.glob(os.path.join(out, "trace_pipe", "**", "*kernel_stats.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if any(k in row.get("Name", "") for k in KERNELS):
+                    print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
     print("== PMC (per dispatch averages, per kernel) ==")
     mean = {}
     for f in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
