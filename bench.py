@@ -305,7 +305,9 @@ def roofline_of(workload, w, n, screen_ms, exact_ms, call_ms, sweep):
             "kernel_ms": screen_ms, "second_kernel": "exact_kernel", "second_kernel_ms": exact_ms, "call_ms": call_ms,
             "kernel_ms_note": "kernel_ms / second_kernel_ms come from a separate pass with HIP event markers between the launches "
                               "(mvk_set_profiling), call_ms from events around whole calls; the timed region carries neither, so "
-                              "their sum can exceed ms_per_step by a few per cent",
+                              "their sum can exceed ms_per_step by a few per cent.  That pass runs one ctx on one stream (launches back to "
+                              "back: a launch duration; profiles/<round>/<workload>_summary.txt, first kernel-stats block, is rocprofv3's "
+                              "figure for the same) -- in the pipe, where ms_per_step comes from, two contexts' kernels share the chip",
             "bytes_per_check": b_alg, "flop_per_check_uncullable": f_model, "flop_per_check_allpairs": f_alg,
             "achieved_uncullable_tflops": n * f_model / t / 1e12,
             "cull_gain_vs_allpairs": n * f_alg / t / 1e12 / PEAK_FP64_VALU_TFLOPS,
