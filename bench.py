@@ -561,6 +561,8 @@ def main():
     ap.add_argument("--overlap-exchange", action="store_true", help="issue the exchange on a second stream (mvk_exchange_masks_dev)")
     ap.add_argument("--count-every-step", action="store_true", help="count the valid bits of the gathered masks every step, not only after the last")
     ap.add_argument("--one-ctx", action="store_true", help="headline through one ctx on one stream (the round-2 form) instead of mvk_pipe_* with two contexts")
+    ap.add_argument("--pipe-timeout", type=float, default=180.0, help="N > 1: seconds the pipelined exchange loop may take before the "
+                    "line is printed from the one-ctx loop's figures instead (a guard for a path no single-GPU box can rehearse)")
     ap.add_argument("--slots", type=int, default=4, help="exchange buffer sets: how many steps the host may run ahead of the exchange")
     ap.add_argument("--cold-steps", type=int, default=20, help="N = 1: timed steps of the from-cold pass before the pre-warm (0: skip)")
     ap.add_argument("--rehearse-exchange", action="store_true",
@@ -812,6 +814,32 @@ def main():
     # one communicator per lane): the other lane's kernels run beside it, no event crosses streams, the host never
     # waits.  Every rank runs this loop (it holds collectives); the figures of the one-ctx loop above are kept beside it.
     pipe_res = None
+    watchdog = None
+    if exchange and not args.one_ctx and comm is not None and comm_b is not None:
+        # Two lanes, a communicator each, collectives on two streams: rehearsed with communicators of one rank only (a
+        # one-GPU box cannot hold two ranks).  Should that loop ever fail to come back on a real node, the K steps through
+        # one ctx above are measured already: print the line from them, say so, and leave.
+        import threading
+
+        def bail():
+            if rank == 0:
+                emit_line({"metric": "state validity checks/sec", "value": world * n * args.steps / elapsed, "unit": "checks/s",
+                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": args.prewarm,
+                           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                           "dtype": "f64", "data": "synthetic",
+                           "config": {"workload": f"{w.name}: {kind.upper()} {NL}-link, joints+base, {n} samples/GPU, {M} box obstacles, "
+                                                  f"{P} robot primitives, flags as packed mask", "samples_per_gpu": n, "obstacles": M,
+                                      "links": NL, "parallelism": f"shard{world}"},
+                           "pipeline": None,
+                           "pipe_fallback": f"the pipelined exchange loop did not finish within {args.pipe_timeout:.0f} s: value is the "
+                                            "same K steps through one ctx with the all-gather behind the kernels on the launch stream",
+                           "rccl_ranks": lib.mvk_comm_world(comm), "exchange_ms": exchange_ms,
+                           "exchange_by": "libmvk.so (mvk_gather_mask_dev -> ncclAllGather, csrc/mvk_dist.cpp)"})
+            sys.stdout.flush()
+            os._exit(0)
+        watchdog = threading.Timer(args.pipe_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
     if not args.one_ctx and (not exchange or (comm is not None and comm_b is not None)):
         import ctypes as C2
         from motion_planning_amd import _abi as A2
@@ -863,6 +891,8 @@ def main():
                     "masks_equal_one_ctx": bool(torch.equal(p_masks[last], d_masks[(args.steps - 1) % n_slot])) if not sweep or world == 1 else None,
                     "gathered_equals_one_ctx": bool(torch.equal(p_alls[last], d_alls[(args.steps - 1) % n_slot])) if exchange else None}
         pipe.close()
+    if watchdog is not None:
+        watchdog.cancel()
 
     if rank == 0:
         valid = int(sum(bin(int(x) & 0xFFFFFFFFFFFFFFFF).count("1") for x in d_mask.cpu().numpy()[:4096]))
