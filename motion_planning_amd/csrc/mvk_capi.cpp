@@ -21,8 +21,12 @@
 namespace mvk {
 
 static thread_local char g_err[512] = "";
+static thread_local int g_code = MVK_OK;  // the code of the latest fail() on this thread (for entry points that return a pointer)
+
+int last_code() { return g_code; }
 
 int fail(int code, const char* fmt, ...) {
+  g_code = code;
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);

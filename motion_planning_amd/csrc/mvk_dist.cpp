@@ -55,7 +55,7 @@ const Rccl& rccl() {
 }
 
 int need_rccl() {
-  if (!rccl().ok) return fail(MVK_ERR_NO_DEVICE, "RCCL is not available (dlopen of librccl.so.1 failed: %s)", dlerror() ? dlerror() : "symbols missing");
+  if (!rccl().ok) return fail(MVK_ERR_NO_DEVICE, "RCCL is not available (%s)", rccl().handle ? "librccl.so.1 lacks a symbol this file binds" : "dlopen of librccl.so.1 failed");
   return MVK_OK;
 }
 
@@ -183,6 +183,7 @@ extern "C" int mvk_exchange_masks_dev(mvk_comm* c, int slot, const uint64_t* d_s
                                       uint64_t* d_count, void* producer_stream, void* exchange_stream) {
   if (!c || !d_shard || !d_all || slot < 0 || slot >= kExchangeSlots) return fail(MVK_ERR_INVALID_ARG, "mvk_exchange_masks_dev: bad argument");
   if (words_per_rank == 0) return MVK_OK;
+  HIPD_TRY(hipSetDevice(c->device));
   hipStream_t ps = static_cast<hipStream_t>(producer_stream), xs = static_cast<hipStream_t>(exchange_stream);
   if (ps != xs) {
     HIPD_TRY(hipEventRecord(c->ev_ready[slot], ps));
@@ -261,7 +262,12 @@ extern "C" int mvk_allreduce_stats(mvk_comm* c, const mvk_stats* local, uint64_t
 // with records that reached it by any other channel; the gloo tests pin the rule against the Python layer)
 extern "C" int mvk_merge_stats(const mvk_stats* locals, const uint64_t* offsets, int world, mvk_stats* global) {
   if (!locals || !offsets || !global || world < 1) return fail(MVK_ERR_INVALID_ARG, "mvk_merge_stats: bad argument");
-  std::vector<StatsRec> recs(static_cast<size_t>(world));
+  std::vector<StatsRec> recs;
+  try {
+    recs.resize(static_cast<size_t>(world));
+  } catch (const std::bad_alloc&) {  // (no exception crosses the ABI)
+    return fail(MVK_ERR_CAPACITY, "mvk_merge_stats: out of host memory for %d records", world);
+  }
   for (int r = 0; r < world; ++r) {
     const mvk_stats& l = locals[r];
     recs[r].count[0] = l.n; recs[r].count[1] = l.valid_count; recs[r].count[2] = l.band_count;

@@ -30,6 +30,7 @@ struct mvk_pipe {
 };
 
 using mvk::fail;
+namespace mvk { int last_code(); }  // mvk_capi.cpp: the code of this thread's latest failure (mvk_create returns a pointer)
 
 extern "C" int mvk_pipe_create(const mvk_model* model, const mvk_box* boxes, size_t n_boxes, const mvk_params* params, int device,
                                int depth, mvk_pipe** out) {
@@ -47,7 +48,11 @@ extern "C" int mvk_pipe_create(const mvk_model* model, const mvk_box* boxes, siz
   int prio_least = 0, prio_greatest = 0;
   for (int i = 0; i < depth; ++i) {
     p->ctx[i] = mvk_create(model, boxes, n_boxes, params, device);  // (sets the device; its own error text on failure)
-    if (!p->ctx[i]) { mvk_pipe_destroy(p); return MVK_ERR_INVALID_ARG; }
+    if (!p->ctx[i]) {  // (the text and the code are mvk_create's: no device, a bad model, ...)
+      const int rc = mvk::last_code();
+      mvk_pipe_destroy(p);
+      return rc != MVK_OK ? rc : MVK_ERR_INVALID_ARG;
+    }
     p->depth = i + 1;
     if (i == 0 && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
     const int levels = prio_least - prio_greatest + 1;  // (numerically, the greatest priority is the smallest value)

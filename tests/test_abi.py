@@ -78,6 +78,10 @@ def test_no_device_means_loud_failure_not_fallback():
     with pytest.raises(mp.MvkError) as e:          # the pipe owns contexts: the same refusal, nothing half-built
         mp.Pipe(m, np.zeros((0, 10)), p, depth=2)
     assert "no HIP device" in str(e.value) or "not gfx950" in str(e.value)
+    out = C.c_void_p()
+    empty = np.zeros((0, 10))   # (the pipe returns the code of the mvk_create that failed, not a generic one)
+    rc = lib.mvk_pipe_create(C.byref(m), empty.ctypes.data_as(A.PB), 0, C.byref(p), 0, 2, C.byref(out))
+    assert rc == A.ERR_NO_DEVICE and not out.value
     with pytest.raises(mp.MvkError):
         mp.Pipe(m, np.zeros((0, 10)), p, depth=0)
     assert lib.mvk_pipe_depth(None) == 0 and not lib.mvk_pipe_ctx(None, 0) and not lib.mvk_pipe_stream(None, 0)
