@@ -6,6 +6,8 @@
 // device is usable every compute entry point returns MVK_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -13,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "mvk_internal.h"
@@ -409,6 +412,31 @@ int boxes_to_obs(const mvk_box* boxes, size_t n, std::vector<DevObs>& host) {
   return MVK_OK;
 }
 
+// Host threads mvk_set_scene may use (the four grids are independent builds, the probe distances independent sums):
+// at most four, fewer on small hosts; MVK_SCENE_THREADS=1 keeps everything on the calling thread.  Workers only touch
+// their own outputs and never call HIP or fail() (whose text is per thread): every upload and every error is the caller's.
+int scene_threads() {
+  int want = 4;
+  if (const char* ov = std::getenv("MVK_SCENE_THREADS")) if (std::atoi(ov) >= 1) want = std::atoi(ov);
+  const unsigned hw = std::thread::hardware_concurrency();
+  if (hw >= 1 && static_cast<unsigned>(want) > hw) want = static_cast<int>(hw);
+  return std::max(1, std::min(want, 16));
+}
+
+// runs job(0) .. job(n_jobs - 1), on up to `threads` threads (the caller's included); a thread that cannot be started
+// leaves its jobs to the caller
+template <class F>
+void run_jobs(int n_jobs, int threads, F&& job) {
+  std::atomic<int> next{0};
+  auto work = [&] { for (int k = next.fetch_add(1); k < n_jobs; k = next.fetch_add(1)) job(k); };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads && t < n_jobs; ++t) {
+    try { pool.emplace_back(work); } catch (...) { break; }
+  }
+  work();
+  for (auto& th : pool) th.join();
+}
+
 // Distance grids of the distance kernels (full path: minimum distance per state; avoidance rows: nearest box per
 // primitive).  A primitive whose centre lies in a cell sees in that cell's list every box within
 // radius = (largest primitive bounding radius + slack) of the centre, so whenever an upper bound <= slack of
@@ -446,7 +474,11 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
     const double u = static_cast<double>(rng >> 11) * (1.0 / 9007199254740992.0);
     probe[i] = lo[i % 3] + u * (hi[i % 3] - lo[i % 3]);
   }
-  for (int i = 0; i < kProbe; ++i) {
+  const int threads = scene_threads();
+  const auto t_probe0 = std::chrono::steady_clock::now();
+  constexpr int kProbeChunk = 64;
+  run_jobs((kProbe + kProbeChunk - 1) / kProbeChunk, threads, [&](int job) {
+  for (int i = job * kProbeChunk; i < std::min(kProbe, (job + 1) * kProbeChunk); ++i) {
     double best2 = INFINITY;
     for (size_t b = 0; b < n; ++b) {
       const DevObs& o = host[b];
@@ -460,30 +492,61 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
     }
     dist[i] = std::sqrt(best2);
   }
+  });
   std::sort(dist.begin(), dist.end());
-  for (int g = 0; g < 2; ++g) {
+  const auto t_build0 = std::chrono::steady_clock::now();
+  // the three builds side by side (jobs 0, 1: the distance grids; job 2: the far grid), then the uploads from here
+  GridHost dgh[2], fgh;
+  bool dbuilt[2] = {false, false}, fbuilt = false;
+  double dmean[2] = {0.0, 0.0};
+  const bool by_bound = !(std::getenv("MVK_NO_GRID_BOUNDS") && std::getenv("MVK_NO_GRID_BOUNDS")[0] == '1');
+  bool far_wanted = true;
+  if (const char* off = std::getenv("MVK_NO_FAR_GRID")) if (off[0] == '1') far_wanted = false;  // diagnostics, tests
+  double diag = 0.0;
+  for (int k = 0; k < 3; ++k) diag += (hi[k] - lo[k]) * (hi[k] - lo[k]);
+  const double far_margin = std::fmin(std::fmax(c->extras.reach, 0.5), 4.0);
+  const double far_pad = 8.0 * static_cast<double>(c->f32_delta) + 4e-6 * (std::sqrt(diag) + 2.0 * far_margin) + 1e-6;
+  // reach: the largest radius term any walk asks with -- the avoidance rows' group walks use grp_rq (a member off the
+  // leader's centre by o needs the boxes within radius + 2 o of the leader's nearest-box distance)
+  double far_reach = rb;
+  for (int gi = 0; gi < c->extras.n_grp; ++gi) far_reach = std::fmax(far_reach, c->extras.grp_rq[gi]);
+  run_jobs(3, threads, [&](int job) {
+    if (job == 2) {
+      // (built whenever a distance grid may exist; dropped below if neither does)
+      if (far_wanted) fbuilt = build_far_grid(host.data(), n, far_reach, far_margin, far_pad, fgh) == MVK_OK;
+      return;
+    }
+    const int g = job;
     int pct = g == 0 ? 25 : 95;  // (profiles/pct_sweep.sh: with the second grid behind it the first one pays off small)
     if (const char* ov = std::getenv("MVK_DISTANCE_GRID_PCT")) if (std::atoi(ov) > 0 && std::atoi(ov) < 100) pct = std::atoi(ov);  // diagnostics
     if (g == 1) if (const char* ov = std::getenv("MVK_DISTANCE_GRID_PCT2")) if (std::atoi(ov) > 0 && std::atoi(ov) < 100) pct = std::atoi(ov);
     double slack = std::fmin(std::fmax(dist[(kProbe * pct) / 100], 0.05), 4.0);
-    GridHost gh;
-    bool built = false;
-    // lists sorted by the box-to-cell lower bound, so that a walk stops early (diagnostics: MVK_NO_GRID_BOUNDS=1)
-    const bool by_bound = !(std::getenv("MVK_NO_GRID_BOUNDS") && std::getenv("MVK_NO_GRID_BOUNDS")[0] == '1');
-    // the second grid's cells: with bounds, finer cells end the walks sooner (a box's bound is taken against the whole
+    // lists sorted by the box-to-cell lower bound, so that a walk stops early (diagnostics: MVK_NO_GRID_BOUNDS=1).
+    // The second grid's cells: with bounds, finer cells end the walks sooner (a box's bound is taken against the whole
     // cell); the first grid's cells are as fine as the cell budget allows already
     double cell_frac = (by_bound && g == 1) ? 0.25 : 0.5;
     if (const char* ov = std::getenv("MVK_GRID_CELL_FRAC")) if (g == 1 && std::atof(ov) >= 0.05 && std::atof(ov) <= 1.0) cell_frac = std::atof(ov);  // diagnostics
     double rbg = rb;  // (the avoidance rows' walks ask with grp_rq)
     if (g == 1) for (int gi = 0; gi < c->extras.n_grp; ++gi) rbg = std::fmax(rbg, c->extras.grp_rq[gi]);
-    for (int attempt = 0; attempt < 3 && !built; ++attempt, slack *= 0.5) built = build_grid(host.data(), n, rbg + slack, gh, by_bound, 4.0 * static_cast<double>(c->f32_delta), cell_frac) == MVK_OK;
-    if (!built) continue;  // too dense for the grid's budget: the sweep stays
+    bool built = false;
+    for (int attempt = 0; attempt < 3 && !built; ++attempt, slack *= 0.5) built = build_grid(host.data(), n, rbg + slack, dgh[g], by_bound, 4.0 * static_cast<double>(c->f32_delta), cell_frac) == MVK_OK;
+    if (!built) return;  // too dense for the grid's budget: the sweep stays
     double mean_len = 0.0;
     for (int i = 0; i < kProbe; ++i) {
       const uint16_t* ids;
-      mean_len += grid_query(gh, &probe[3 * i], &ids);
+      mean_len += grid_query(dgh[g], &probe[3 * i], &ids);
     }
-    mean_len /= kProbe;
+    dmean[g] = mean_len / kProbe;
+    dbuilt[g] = true;
+  });
+  if (std::getenv("MVK_DISTANCE_GRID_TRACE"))
+    std::fprintf(stderr, "mvk: %d host thread(s): probe distances %.1f ms, distance grids + far grid %.1f ms\n", threads,
+                 std::chrono::duration<double, std::milli>(t_build0 - t_probe0).count(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count());
+  for (int g = 0; g < 2; ++g) {
+    if (!dbuilt[g]) continue;
+    GridHost& gh = dgh[g];
+    const double mean_len = dmean[g];
     if (mean_len > 0.25 * static_cast<double>(n)) continue;
     if (int rc = c->dgrid_start[g].reserve(sizeof(uint32_t) * gh.start.size())) return rc;
     if (int rc = c->dgrid_items[g].reserve(sizeof(uint16_t) * (gh.items.size() + kGridGroup))) return rc;
@@ -510,19 +573,11 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
   // Behind them, for the primitives neither can answer (farther from every box than the second grid's slack: open
   // space, the rim of the obstacles' volume): the far grid, whose lists are complete at any distance.  It replaces
   // the sweep over all boxes inside the boxes' bound inflated by the robot's reach.
-  bool far_on = c->dgrid[0].start != nullptr || c->dgrid[1].start != nullptr;
-  if (const char* off = std::getenv("MVK_NO_FAR_GRID")) if (off[0] == '1') far_on = false;  // diagnostics, tests
+  const bool far_on = far_wanted && (c->dgrid[0].start != nullptr || c->dgrid[1].start != nullptr);
   if (far_on) {
-    double diag = 0.0;
-    for (int k = 0; k < 3; ++k) diag += (hi[k] - lo[k]) * (hi[k] - lo[k]);
-    const double margin = std::fmin(std::fmax(c->extras.reach, 0.5), 4.0);
-    const double pad = 8.0 * static_cast<double>(c->f32_delta) + 4e-6 * (std::sqrt(diag) + 2.0 * margin) + 1e-6;
-    GridHost gh;
-    // reach: the largest radius term any walk asks with -- the avoidance rows' group walks use grp_rq (a member off the
-    // leader's centre by o needs the boxes within radius + 2 o of the leader's nearest-box distance)
-    double far_reach = rb;
-    for (int gi = 0; gi < c->extras.n_grp; ++gi) far_reach = std::fmax(far_reach, c->extras.grp_rq[gi]);
-    if (build_far_grid(host.data(), n, far_reach, margin, pad, gh) == MVK_OK) {
+    const double margin = far_margin;
+    GridHost& gh = fgh;
+    if (fbuilt) {
       if (int rc = c->fgrid_start.reserve(sizeof(uint32_t) * gh.start.size())) return rc;
       if (int rc = c->fgrid_items.reserve(sizeof(uint16_t) * (gh.items.size() + kGridGroup))) return rc;
       HIP_TRY(hipMemcpy(c->fgrid_start.p, gh.start.data(), sizeof(uint32_t) * gh.start.size(), hipMemcpyHostToDevice));
@@ -573,7 +628,10 @@ int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
   const double fk_err = 16.0 * 5.9604645e-8 * (c->model.n_seg + 1) * range + static_cast<double>(c->extras.f32.err_p);
   rq += 2.0 * fk_err;
   GridHost gh;
+  const auto t_flag0 = std::chrono::steady_clock::now();
   if (int rc = build_grid(host.data(), n, rq, gh)) return rc;
+  if (std::getenv("MVK_DISTANCE_GRID_TRACE"))
+    std::fprintf(stderr, "mvk: flag grid built in %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_flag0).count());
   if (int rc = c->obs.reserve(sizeof(DevObs) * (n ? n : 1))) return rc;
   if (int rc = c->obsf.reserve(sizeof(DevObsF) * (n + 1))) return rc;
   if (int rc = c->grid_start.reserve(sizeof(uint32_t) * gh.start.size())) return rc;
