@@ -72,8 +72,7 @@ def test_random_scene_all_kernel_families(kind, n_links, n_boxes):
         assert np.array_equal(np.isfinite(got["min_dist"][:k]), f)
         assert np.allclose(got["min_dist"][:k][f], ref["min_dist"][sl][f], rtol=0, atol=1e-9)
         fm = np.isfinite(ref["margin"][sl])
-        tol = 1e-9 + common.margin_rtol(model, ref["thrust"][:, sl]) * np.abs(ref["margin"][sl])   # (1e-5 but for near-singular thrust solves)
-        assert np.all(np.abs(got["margin"][:k] - ref["margin"][sl])[fm] <= tol[fm])
+        assert np.all(common.margins_agree(model, st[:, sl], got["margin"][:k], ref["margin"][sl])[fm])   # (1e-5; near-singular thrust solves: see there)
     assert np.array_equal(big["min_dist"][:n], big["min_dist"][n:], equal_nan=True)
     assert np.array_equal(big["min_dist"][:300], small["min_dist"], equal_nan=True)     # the two kernel sizes: same bits
     assert np.array_equal(big["min_dist"][40:41], one["min_dist"], equal_nan=True)
