@@ -160,7 +160,8 @@ def margins_agree(model, states, got, ref):
     NumPy restatement (oracle/np_vspec.py).  Such states are unstable by orders of magnitude: no flag is in question."""
     import os, sys
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
-    ok = np.abs(got - ref) <= 1e-9 + 1e-5 * np.abs(ref)
+    with np.errstate(invalid="ignore"):   # (inf - inf where both report a non-finite margin)
+        ok = np.abs(got - ref) <= 1e-9 + 1e-5 * np.abs(ref)
     ok |= ~np.isfinite(ref)
     if not ok.all():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
