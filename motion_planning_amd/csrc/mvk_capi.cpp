@@ -101,6 +101,7 @@ void quat_to_rows(const double q[4], double R[9]) {
 using namespace mvk;
 
 namespace mvk {
+void grid_build_threads(int threads);  // mvk_grid.cpp: host threads of the build_grid calls made from the calling thread
 int edges_submit_two_launches(mvk_ctx* c);
 }
 
@@ -517,6 +518,7 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
       return;
     }
     const int g = job;
+    grid_build_threads(threads);
     int pct = g == 0 ? 25 : 95;  // (profiles/pct_sweep.sh: with the second grid behind it the first one pays off small)
     if (const char* ov = std::getenv("MVK_DISTANCE_GRID_PCT")) if (std::atoi(ov) > 0 && std::atoi(ov) < 100) pct = std::atoi(ov);  // diagnostics
     if (g == 1) if (const char* ov = std::getenv("MVK_DISTANCE_GRID_PCT2")) if (std::atoi(ov) > 0 && std::atoi(ov) < 100) pct = std::atoi(ov);
@@ -629,6 +631,7 @@ int upload_scene(mvk_ctx* c, const mvk_box* boxes, size_t n) {
   rq += 2.0 * fk_err;
   GridHost gh;
   const auto t_flag0 = std::chrono::steady_clock::now();
+  grid_build_threads(scene_threads());
   if (int rc = build_grid(host.data(), n, rq, gh)) return rc;
   if (std::getenv("MVK_DISTANCE_GRID_TRACE"))
     std::fprintf(stderr, "mvk: flag grid built in %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_flag0).count());

@@ -52,7 +52,35 @@ double cube_box_lower_bound(const DevObs& o, const double ext[3], const double c
 
 }  // namespace
 
+namespace {
+// fn(t, lo, hi) for T contiguous ranges of [0, n), range t on its own thread (range 0 on the caller's); a thread that
+// cannot be started leaves its range to the caller
+template <class F>
+void for_ranges(size_t n, int T, F&& fn) {
+  std::vector<std::thread> pool;
+  std::vector<char> started(static_cast<size_t>(T), 0);
+  for (int t = 1; t < T; ++t) {
+    try {
+      pool.emplace_back([&fn, n, T, t] { fn(t, n * static_cast<size_t>(t) / T, n * static_cast<size_t>(t + 1) / T); });
+      started[t] = 1;
+    } catch (...) {
+      break;
+    }
+  }
+  fn(0, size_t{0}, n / static_cast<size_t>(T));
+  for (int t = 1; t < T; ++t)
+    if (!started[t]) fn(t, n * static_cast<size_t>(t) / T, n * static_cast<size_t>(t + 1) / T);
+  for (auto& th : pool) th.join();
+}
+}  // namespace
+
+// host threads of the builds started from the calling thread (mvk_capi.cpp sets it per thread before a build; the
+// result does not depend on it)
+static thread_local int g_build_threads = 1;
+void grid_build_threads(int threads) { g_build_threads = threads < 1 ? 1 : threads; }
+
 int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_bound, double pad, double cell_frac) {
+  const int threads = g_build_threads;
   g.start.clear();
   g.items.clear();
   g.glb.clear();
@@ -108,23 +136,32 @@ int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_
     };
     std::vector<uint32_t> count(ncell, 0u);
     // the (cell, bound) hits of the counting pass are kept and replayed by the filling pass (the bound against a cell is
-    // the costly part of either); beyond kHitKeep hits the filling pass computes them again
+    // the costly part of either); beyond kHitKeep hits the filling pass computes them again.  The counting pass -- a
+    // bound per (box, cell in the box's reach), most of the build -- runs over contiguous box ranges on `threads`
+    // threads, each with its own hit list; the lists are replayed in range order, which is box order: the same grid.
     struct Hit { uint32_t cell; float lb; };
     constexpr size_t kHitKeep = size_t{1} << 24;
-    std::vector<Hit> hits;
-    std::vector<uint32_t> hits_of_box(n + 1, 0u);
-    bool kept = true;
-    for (size_t i = 0; i < n; ++i) {
-      hits_of_box[i] = static_cast<uint32_t>(hits.size());
-      for_cells(i, [&](uint64_t c, double lb) {
-        ++count[c];
-        if (kept) {
-          if (hits.size() < kHitKeep) hits.push_back(Hit{static_cast<uint32_t>(c), static_cast<float>(lb)});
-          else kept = false;
-        }
-      });
+    const int T = static_cast<int>(std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(std::max(threads, 1)), size_t{16}, n / 64 + 1})));
+    std::vector<std::vector<Hit>> hits_t(static_cast<size_t>(T));
+    std::vector<uint32_t> hits_of_box(n, 0u);
+    std::atomic<size_t> n_hits{0};
+    for_ranges(n, T, [&](int t, size_t b0, size_t b1) {
+      std::vector<Hit>& mine = hits_t[static_cast<size_t>(t)];
+      for (size_t i = b0; i < b1 && n_hits.load(std::memory_order_relaxed) <= kHitKeep; ++i) {
+        const size_t before = mine.size();
+        for_cells(i, [&](uint64_t c, double lb) { mine.push_back(Hit{static_cast<uint32_t>(c), static_cast<float>(lb)}); });
+        hits_of_box[i] = static_cast<uint32_t>(mine.size() - before);
+        n_hits.fetch_add(mine.size() - before, std::memory_order_relaxed);
+      }
+    });
+    const bool kept = n_hits.load() <= kHitKeep;
+    if (kept) {
+      for (const auto& list : hits_t)
+        for (const Hit& e : list) ++count[e.cell];
+    } else {  // (a scene beyond the kept hits: count without keeping, the filling pass computes the bounds again)
+      hits_t.clear();
+      for (size_t i = 0; i < n; ++i) for_cells(i, [&](uint64_t c, double) { ++count[c]; });
     }
-    hits_of_box[n] = static_cast<uint32_t>(hits.size());
     uint64_t groups = 0;
     for (uint64_t c = 0; c < ncell; ++c) groups += (count[c] + kGridGroup - 1) / kGridGroup;
     if (groups * kGridGroup > kGridMaxItems) continue;
@@ -147,23 +184,36 @@ int build_grid(const DevObs* obs, size_t n, double radius, GridHost& g, bool by_
       // half an ulp above the double it came from: the relative 1e-6 covers that as well)
       if (by_bound) lbs[at_item] = static_cast<float>(std::max(0.0, lb * (1.0 - 1e-6) - pad - 1e-6));
     };
-    for (size_t i = 0; i < n; ++i) {  // boxes in ascending id order inside every cell
-      if (kept) for (uint32_t e = hits_of_box[i]; e < hits_of_box[i + 1]; ++e) place(i, hits[e].cell, static_cast<double>(hits[e].lb));
-      else for_cells(i, [&](uint64_t c, double lb) { place(i, c, lb); });
+    // boxes in ascending id order inside every cell: the hit lists are in box order (a list per box range, a box's hits
+    // in for_cells' order), and the box of a hit is the one whose range the replay has reached
+    if (kept) {
+      for (int t = 0; t < T; ++t) {
+        const std::vector<Hit>& list = hits_t[static_cast<size_t>(t)];
+        size_t e = 0;
+        for (size_t i = n * static_cast<size_t>(t) / T; i < n * static_cast<size_t>(t + 1) / T; ++i)
+          for (uint32_t k = 0; k < hits_of_box[i]; ++k, ++e) place(i, list[e].cell, static_cast<double>(list[e].lb));
+      }
+    } else {
+      for (size_t i = 0; i < n; ++i) for_cells(i, [&](uint64_t c, double lb) { place(i, c, lb); });
     }
     if (by_bound) {  // ... then by bound, ascending (ties: by id), the padding last
       g.glb.assign(at, 0.0f);
-      std::vector<std::pair<float, uint16_t>> cell;
-      for (uint64_t c = 0; c < ncell; ++c) {
-        const size_t b0 = static_cast<size_t>(g.start[c]) * kGridGroup;
-        cell.clear();
-        for (uint32_t e = 0; e < count[c]; ++e) cell.emplace_back(lbs[b0 + e], g.items[b0 + e]);
-        std::sort(cell.begin(), cell.end());
-        for (uint32_t e = 0; e < count[c]; ++e) {
-          g.items[b0 + e] = cell[e].second;
-          if (e % kGridGroup == 0) g.glb[g.start[c] + e / kGridGroup] = std::nextafterf(cell[e].first, -INFINITY) < 0.0f ? 0.0f : std::nextafterf(cell[e].first, -INFINITY);
+      constexpr uint64_t kChunk = 512;  // cells per ticket: the lists are uneven across the volume
+      std::atomic<uint64_t> ticket{0};
+      for_ranges(static_cast<size_t>(T), T, [&](int, size_t, size_t) {
+        std::vector<std::pair<float, uint16_t>> cell;
+        for (uint64_t c0 = ticket.fetch_add(kChunk); c0 < ncell; c0 = ticket.fetch_add(kChunk))
+        for (uint64_t c = c0; c < std::min<uint64_t>(ncell, c0 + kChunk); ++c) {
+          const size_t b0 = static_cast<size_t>(g.start[c]) * kGridGroup;
+          cell.clear();
+          for (uint32_t e = 0; e < count[c]; ++e) cell.emplace_back(lbs[b0 + e], g.items[b0 + e]);
+          std::sort(cell.begin(), cell.end());
+          for (uint32_t e = 0; e < count[c]; ++e) {
+            g.items[b0 + e] = cell[e].second;
+            if (e % kGridGroup == 0) g.glb[g.start[c] + e / kGridGroup] = std::nextafterf(cell[e].first, -INFINITY) < 0.0f ? 0.0f : std::nextafterf(cell[e].first, -INFINITY);
+          }
         }
-      }
+      });
     }
     for (int k = 0; k < 3; ++k) { g.origin[k] = lo[k]; g.n[k] = dim[k]; }
     g.h = h;

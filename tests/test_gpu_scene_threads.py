@@ -1,5 +1,6 @@
 """mvk_set_scene builds its grids on up to four host threads (mvk_capi.cpp upload_distance_grids: the probe distances in
-chunks, then the two distance grids and the far grid side by side).  The builds are the same code on the same inputs,
+chunks, then the two distance grids and the far grid side by side; mvk_grid.cpp build_grid: the counting pass over box
+ranges, the per-cell sorts over chunks of cells).  The builds are the same code on the same inputs,
 so every output must carry the bits of the one-thread build (MVK_SCENE_THREADS=1).
 
 Reference: MotionPlanning::setScene (motion_planning.cpp:167-175) replaces the obstacle set; what the library derives
