@@ -513,6 +513,7 @@ int upload_distance_grids(mvk_ctx* c, const std::vector<DevObs>& host) {
   for (int gi = 0; gi < c->extras.n_grp; ++gi) far_reach = std::fmax(far_reach, c->extras.grp_rq[gi]);
   run_jobs(3, threads, [&](int job) {
     if (job == 2) {
+      grid_build_threads(threads);
       // (built whenever a distance grid may exist; dropped below if neither does)
       if (far_wanted) fbuilt = build_far_grid(host.data(), n, far_reach, far_margin, far_pad, fgh) == MVK_OK;
       return;

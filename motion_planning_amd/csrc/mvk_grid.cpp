@@ -304,8 +304,10 @@ int build_far_grid(const DevObs* obs, size_t n, double reach, double margin, dou
     }
   };
   {
+    // (one thread when the caller asked for one -- MVK_SCENE_THREADS=1, the host diagnostics; else up to 8: this build
+    // is cells x boxes of cheap tests, the longest of the three that run side by side)
     const unsigned hw = std::thread::hardware_concurrency();
-    const unsigned nt = std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
+    const unsigned nt = g_build_threads <= 1 ? 1u : std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
     work();
