@@ -135,6 +135,17 @@ int use(mvk_ctx* ctx) {
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
 
 
+def test_integration_examples_compile_and_link(tmp_path):
+    """the calls INTEGRATION.md shows (pipe, multi-GPU exchange, fp32 outputs), as C against mvk.h and libmvk.so"""
+    import subprocess
+    libdir = os.path.join(ROOT, "motion_planning_amd", "lib")
+    if not os.path.exists(os.path.join(libdir, "libmvk.so")):
+        pytest.skip("library not built here")
+    out = tmp_path / "libexamples.so"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-Wl,--no-undefined", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "examples", "integration_snippets.c"), "-L", libdir, "-lmvk", "-o", str(out)])
+
+
 def test_adapter_check_library_is_built_and_exports_its_entry_points():
     """the runnable form of the adapter (csrc/mvk_adapter_check.cpp); it is RUN by tests/test_gpu_adapter.py"""
     A.load()
