@@ -4,7 +4,8 @@ config 5 -- 2^26 samples of the HYDRUS-8 joint space generated in the kernel, 2^
 one launch equals its eight 2^20-sample launches word for word, a shard through a two-context pipe equals the shard
 through one ctx, the valid counts of the shards add up to the count of the gathered mask, and a slice of every shard
 agrees with the oracle on the materialised states;
-config 2 / 3 -- 2^20 samples: a batch equals the concatenation of its halves, the mask equals the flags.
+config 2 / 3 -- 2^20 samples: a batch equals the concatenation of its halves, the mask equals the flags;
+config 4 -- 65,536 edges x 64 steps: the batch equals its quarters, a sample of the edges against the oracle.
 
 Reference: MotionPlanning::isStateValid (motion_planning.cpp:76-164); the sweep mirrors
 sampling_based_method/scripts/state_validation_l4.py:46-68."""
@@ -81,4 +82,31 @@ def test_full_batch_equals_its_halves(make):
     assert torch.equal(whole, halves)
     bits = np.unpackbits(whole.cpu().numpy().view(np.uint8), bitorder="little")
     assert np.array_equal(bits, flags.cpu().numpy())
+    eng.close()
+
+
+def test_config4_full_edge_batch_equals_its_parts():
+    """65,536 edges x 64 steps: the batch equals its four quarters edge for edge (verdict and first invalid step), and a
+    sample of the edges agrees with the oracle's discrete motion validator"""
+    model, params, boxes, s1, s2, nd = common.config4(n_edges=1 << 16)
+    E = s1.shape[1]
+    eng = mp.Engine(model, boxes, params)
+    d1, d2 = torch.from_numpy(s1).cuda(), torch.from_numpy(s2).cuda()
+    ok = torch.zeros(E, dtype=torch.uint8, device="cuda")
+    first = torch.zeros(E, dtype=torch.int32, device="cuda")
+    okq = torch.zeros(E, dtype=torch.uint8, device="cuda")
+    firstq = torch.zeros(E, dtype=torch.int32, device="cuda")
+    eng.check_motion_batch_dev(d1, d2, nd, ok, first)
+    q = E // 4
+    for k in range(4):
+        eng.check_motion_batch_dev(d1[:, k * q:(k + 1) * q], d2[:, k * q:(k + 1) * q], nd, okq[k * q:(k + 1) * q], firstq[k * q:(k + 1) * q])
+    torch.cuda.synchronize()
+    assert torch.equal(ok, okq) and torch.equal(first, firstq)
+    idx = np.linspace(0, E - 1, 256).astype(int)
+    nds = np.full(len(idx), nd, np.int32)
+    g_ok, g_first, g_band = O.check_motion_batch(model, boxes, params, np.ascontiguousarray(s1[:, idx]), np.ascontiguousarray(s2[:, idx]), nds)
+    h_ok, h_first = ok.cpu().numpy()[idx], first.cpu().numpy()[idx]
+    diff = (h_ok != g_ok) | (h_first != g_first)
+    assert not np.any(diff & ~g_band.astype(bool))
+    assert 0 < int(ok.sum().item()) < E
     eng.close()
