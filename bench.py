@@ -561,6 +561,7 @@ def main():
     ap.add_argument("--overlap-exchange", action="store_true", help="issue the exchange on a second stream (mvk_exchange_masks_dev)")
     ap.add_argument("--count-every-step", action="store_true", help="count the valid bits of the gathered masks every step, not only after the last")
     ap.add_argument("--one-ctx", action="store_true", help="headline through one ctx on one stream (the round-2 form) instead of mvk_pipe_* with two contexts")
+    ap.add_argument("--pipe-depth", type=int, default=2, help="contexts (lanes) of the headline's pipe, 2..4")
     ap.add_argument("--pipe-timeout", type=float, default=180.0, help="N > 1: seconds the pipelined exchange loop may take before the "
                     "line is printed from the one-ctx loop's figures instead (a guard for a path no single-GPU box can rehearse)")
     ap.add_argument("--slots", type=int, default=4, help="exchange buffer sets: how many steps the host may run ahead of the exchange")
@@ -591,6 +592,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     comm, comm_b = None, None
+    depth = max(2, min(4, args.pipe_depth))
+    lane_comms = []   # the communicators of lanes 1 .. depth - 1 (lane 0 uses comm)
     if exchange and args.exchange == "mvk":
         # the library's own communicators (csrc/mvk_dist.cpp: ncclCommInitRank from libmvk.so); a 128-byte id travels
         # over the process group the launcher set up, which also serves the barrier and the max-over-ranks below.  Two of
@@ -626,10 +629,17 @@ def main():
             args.exchange_fallback = f"mvk_comm_create failed on some rank ({why}): torch.distributed exchange instead"
             print(f"rank {rank}: {args.exchange_fallback}", file=sys.stderr)
         elif not args.one_ctx:
-            comm_b, why = make_comm()
-            if comm_b is None:
-                args.exchange_fallback = f"second communicator failed on some rank ({why}): headline through one ctx"
-                print(f"rank {rank}: {args.exchange_fallback}", file=sys.stderr)
+            for _ in range(1, depth):   # a communicator per lane of the pipe
+                cx, why = make_comm()
+                if cx is None:
+                    args.exchange_fallback = f"a lane's communicator failed on some rank ({why}): headline through one ctx"
+                    print(f"rank {rank}: {args.exchange_fallback}", file=sys.stderr)
+                    for c_ in lane_comms:
+                        lib.mvk_comm_destroy(c_)
+                    lane_comms = []
+                    break
+                lane_comms.append(cx)
+            comm_b = lane_comms[0] if lane_comms else None
 
     if args.workload == "c4":
         return bench_edges(args, world, rank, local_rank, dev)
@@ -844,15 +854,15 @@ def main():
         import ctypes as C2
         from motion_planning_amd import _abi as A2
         plib = A2.load()
-        pipe = mp.Pipe(w.model, w.boxes, w.params, depth=2, device=local_rank)
-        p_slots = max(2, n_slot + (n_slot & 1))   # an even number of buffer sets: a set always returns to the same lane
+        pipe = mp.Pipe(w.model, w.boxes, w.params, depth=depth, device=local_rank)
+        p_slots = depth * max(1, (n_slot + depth - 1) // depth)   # a multiple of the depth: a buffer set always returns to the same lane
         p_masks = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(p_slots)]
         p_alls = [torch.zeros(world * words, dtype=torch.int64, device=dev) for _ in range(p_slots)] if exchange else None
-        p_streams = [C2.c_void_p(plib.mvk_pipe_stream(pipe.pipe, lane)) for lane in range(2)]
-        p_comms = [comm, comm_b]
+        p_streams = [C2.c_void_p(plib.mvk_pipe_stream(pipe.pipe, lane)) for lane in range(depth)]
+        p_comms = [comm] + lane_comms
 
         def pstep(k):
-            # a buffer set always returns to the same lane (p_slots is even), and a lane runs its work in order: the
+            # a buffer set always returns to the same lane (p_slots is a multiple of the depth), and a lane runs its work in order: the
             # all-gather of step k has left the set's mask long before step k + p_slots writes it -- no event, no host wait
             slot = k % p_slots
             if sweep:
@@ -922,8 +932,8 @@ def main():
             "config": {"workload": f"{w.name}: {kind.upper()} {NL}-link, joints+base, {n} samples/GPU, {M} box obstacles, "
                                    f"{P} robot primitives, flags as packed mask" + (", states generated in-kernel (C-space sweep)" if sweep else ""),
                        "samples_per_gpu": n, "obstacles": M, "links": NL, "parallelism": f"shard{world}"},
-            "pipeline": ({"entry_point": "mvk_pipe_sweep_mask" if sweep else "mvk_pipe_is_valid_mask", "contexts": 2, "streams": 2,
-                          "note": "the K timed steps go through the library's pipe: batches alternate between two contexts with a stream each, "
+            "pipeline": ({"entry_point": "mvk_pipe_sweep_mask" if sweep else "mvk_pipe_is_valid_mask", "contexts": depth, "streams": depth,
+                          "note": "the K timed steps go through the library's pipe: batches go round-robin to its contexts, a stream each, "
                                   "so one batch's exact stage runs beside the next one's screen stage (DESIGN.md section 5); per batch the same "
                                   "kernels and bits as one ctx; value_one_ctx / ms_per_step_one_ctx are the same K steps through one ctx on one stream",
                           "masks_equal_one_ctx": pipe_res["masks_equal_one_ctx"], "gathered_equals_one_ctx": pipe_res["gathered_equals_one_ctx"],
@@ -988,8 +998,8 @@ def main():
             leg("fp32_variant", lambda: fp32_variant(eng, w, d_soa, n, dev))
         emit_line(out)
     eng.close()
-    if comm_b is not None:
-        lib.mvk_comm_destroy(comm_b)
+    for c_ in lane_comms:
+        lib.mvk_comm_destroy(c_)
     if comm is not None:
         lib.mvk_comm_destroy(comm)
     if exchange:
