@@ -29,6 +29,14 @@ long long mvk_debug_fused_giveups(mvk_ctx* ctx, int reset);
 int mvk_debug_grid_bounds(const mvk_box* boxes, size_t n_boxes, double radius, double pad, const double* points,
                           size_t n_points, int32_t* counts, int32_t* ids, float* bounds, int cap);
 
+/* mvk_pipe_create looks whether its lanes' streams run side by side (a one-wave spin kernel on two of them: through one
+ * hardware queue the pair takes twice as long) and replaces the stream of a lane that shares a queue with another:
+ * the number of streams it replaced for this pipe (csrc/mvk_pipe.cpp; MVK_PIPE_NO_PROBE=1 skips the look).  -1 for a
+ * null pipe.  mvk_debug_pipe_lanes_overlap runs the same look again on lanes a and b: 1 side by side, 0 one after the
+ * other, -1 the probe failed or a bad argument.  tests/test_gpu_pipe.py. */
+int mvk_debug_pipe_restreamed(const mvk_pipe* pipe);
+int mvk_debug_pipe_lanes_overlap(mvk_pipe* pipe, int lane_a, int lane_b);
+
 #ifdef __cplusplus
 }
 #endif

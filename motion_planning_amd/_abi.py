@@ -221,6 +221,8 @@ DEBUG_PROTOTYPES = {
     "mvk_debug_f32_bounds": (ip, [vp, vp, sz, sz, ip, vp, vp, vp, vp, vp]),
     "mvk_debug_fused_giveups": (C.c_longlong, [vp, ip]),
     "mvk_debug_grid_bounds": (ip, [PB, sz, d, d, vp, sz, vp, vp, vp, ip]),
+    "mvk_debug_pipe_restreamed": (ip, [vp]),
+    "mvk_debug_pipe_lanes_overlap": (ip, [vp, ip, ip]),
 }
 
 

@@ -12,9 +12,11 @@
 // entry point the north star adds.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <new>
 
 #include "mvk_internal.h"
+#include "../../include/mvk_debug.h"
 
 namespace {
 constexpr int kPipeMaxDepth = 8;
@@ -27,10 +29,45 @@ struct mvk_pipe {
   hipStream_t stream[kPipeMaxDepth] = {};
   hipEvent_t done[kPipeMaxDepth] = {};   // recorded behind the lane's latest batch
   hipEvent_t ready = nullptr;            // recorded on a producer stream, waited for by a lane
+  int restreamed = 0;                    // streams replaced at creation because they shared a hardware queue with another lane
 };
 
 using mvk::fail;
-namespace mvk { int last_code(); }  // mvk_capi.cpp: the code of this thread's latest failure (mvk_create returns a pointer)
+namespace mvk {
+int last_code();                              // mvk_capi.cpp: the code of this thread's latest failure (mvk_create returns a pointer)
+int launch_spin(void* stream, unsigned ticks);  // mvk_probe.hip: one wave busy for `ticks` of the 100 MHz wall clock
+}
+
+namespace {
+// Do kernels on streams a and b run side by side?  One wave spins for 30 us on a alone, then one on each: through
+// different hardware queues the second pair takes as long as the first kernel, through one queue twice as long.
+// (-1: the probe itself failed; the caller keeps what it has)
+int lanes_overlap(hipStream_t a, hipStream_t b) {
+  hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+  int verdict = -1;
+  constexpr unsigned kTicks = 3000;
+  do {
+    bool made = true;
+    for (auto& x : e) made = made && hipEventCreate(&x) == hipSuccess;
+    if (!made) break;
+    if (mvk::launch_spin(a, 100) != 0 || mvk::launch_spin(b, 100) != 0) break;  // (code resident, queues awake)
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) break;
+    float t_one = 0.0f, t_a = 0.0f, t_b = 0.0f;
+    if (hipEventRecord(e[0], a) != hipSuccess || mvk::launch_spin(a, kTicks) != 0 || hipEventRecord(e[1], a) != hipSuccess) break;
+    if (hipStreamSynchronize(a) != hipSuccess || hipEventElapsedTime(&t_one, e[0], e[1]) != hipSuccess) break;
+    if (hipEventRecord(e[0], a) != hipSuccess || mvk::launch_spin(a, kTicks) != 0 || mvk::launch_spin(b, kTicks) != 0 ||
+        hipEventRecord(e[1], a) != hipSuccess || hipEventRecord(e[2], b) != hipSuccess)
+      break;
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) break;
+    if (hipEventElapsedTime(&t_a, e[0], e[1]) != hipSuccess || hipEventElapsedTime(&t_b, e[0], e[2]) != hipSuccess) break;
+    verdict = (t_a > t_b ? t_a : t_b) < 1.6f * t_one ? 1 : 0;
+  } while (false);
+  (void)hipGetLastError();
+  for (auto& x : e)
+    if (x) (void)hipEventDestroy(x);
+  return verdict;
+}
+}  // namespace
 
 extern "C" int mvk_pipe_create(const mvk_model* model, const mvk_box* boxes, size_t n_boxes, const mvk_params* params, int device,
                                int depth, mvk_pipe** out) {
@@ -67,6 +104,29 @@ extern "C" int mvk_pipe_create(const mvk_model* model, const mvk_box* boxes, siz
     mvk_pipe_destroy(p);
     return fail(MVK_ERR_HIP, "mvk_pipe_create: event creation failed");
   }
+  // The priorities keep the lanes apart in a process of its own; beside other users of the runtime's queues (a
+  // communicator's streams, a framework's) two lanes were still seen behind one queue now and then -- one run in four of
+  // the exchange rehearsal ran at the speed of one ctx.  So the pipe looks: every lane against lane 0 with the spin
+  // probe, and a lane that does not run beside it gets a fresh stream (the runtime hands the queues out in turn), a few
+  // times at most.  MVK_PIPE_NO_PROBE=1 skips it (diagnostics).
+  const char* no_probe = std::getenv("MVK_PIPE_NO_PROBE");
+  if (depth > 1 && !(no_probe && no_probe[0] == '1')) {
+    for (int i = 1; i < depth; ++i) {
+      for (int attempt = 0; attempt < 6; ++attempt) {
+        bool apart = true;
+        for (int j = 0; j < i && apart; ++j) apart = lanes_overlap(p->stream[j], p->stream[i]) != 0;  // (-1: cannot tell, keep)
+        if (apart) break;
+        ++p->restreamed;
+        hipStream_t fresh = nullptr;
+        int prio = 0;
+        (void)hipStreamGetPriority(p->stream[i], &prio);
+        if (hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); break; }
+        // (the old stream is destroyed after the new one exists, so that the runtime does not hand the same queue back)
+        (void)hipStreamDestroy(p->stream[i]);
+        p->stream[i] = fresh;
+      }
+    }
+  }
   *out = p;
   return MVK_OK;
 }
@@ -84,6 +144,12 @@ extern "C" void mvk_pipe_destroy(mvk_pipe* p) {
   delete p;
 }
 
+extern "C" int mvk_debug_pipe_restreamed(const mvk_pipe* p) { return p ? p->restreamed : -1; }
+extern "C" int mvk_debug_pipe_lanes_overlap(mvk_pipe* p, int a, int b) {
+  if (!p || a < 0 || b < 0 || a >= p->depth || b >= p->depth || a == b) return -1;
+  if (hipSetDevice(p->device) != hipSuccess) return -1;
+  return lanes_overlap(p->stream[a], p->stream[b]);
+}
 extern "C" int mvk_pipe_depth(const mvk_pipe* p) { return p ? p->depth : 0; }
 extern "C" void* mvk_pipe_stream(mvk_pipe* p, int lane) { return (p && lane >= 0 && lane < p->depth) ? static_cast<void*>(p->stream[lane]) : nullptr; }
 extern "C" mvk_ctx* mvk_pipe_ctx(mvk_pipe* p, int lane) { return (p && lane >= 0 && lane < p->depth) ? p->ctx[lane] : nullptr; }

@@ -10,6 +10,7 @@ import pytest
 import common
 import motion_planning_amd as mp
 import oracle_lib as O
+from motion_planning_amd import _abi as A
 
 pytestmark = pytest.mark.gpu
 
@@ -119,3 +120,24 @@ def test_full_path_and_sweep_through_a_pipe_and_errors():
         mp.Pipe(w.model, w.boxes, w.params, depth=0)
     with pytest.raises(mp.MvkError):
         mp.Pipe(w.model, w.boxes, w.params, depth=9)
+
+
+def test_pipe_lanes_run_side_by_side():
+    """mvk_pipe_create probes its lanes with a one-wave spin kernel and replaces a stream that shares a hardware queue
+    with another lane (csrc/mvk_pipe.cpp lanes_overlap): after creation every pair of lanes runs side by side, also
+    when the process holds other streams and earlier pipes have come and gone"""
+    import torch
+    lib = A.load()
+    w = common.config2(n=64, n_boxes=10)
+    others = [torch.cuda.Stream() for _ in range(5)]           # other users of the runtime's queues
+    for cycle in range(4):
+        for depth in (2, 3):
+            pipe = mp.Pipe(w.model, w.boxes, w.params, depth=depth)
+            assert lib.mvk_debug_pipe_restreamed(pipe.pipe) >= 0
+            for a in range(depth):
+                for b in range(a + 1, depth):
+                    assert lib.mvk_debug_pipe_lanes_overlap(pipe.pipe, a, b) == 1, (cycle, depth, a, b, lib.mvk_debug_pipe_restreamed(pipe.pipe))
+            assert lib.mvk_debug_pipe_lanes_overlap(pipe.pipe, 0, 0) == -1 and lib.mvk_debug_pipe_lanes_overlap(pipe.pipe, 0, depth) == -1
+            pipe.close()
+    del others
+    assert lib.mvk_debug_pipe_restreamed(None) == -1
