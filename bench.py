@@ -562,7 +562,7 @@ def main():
     ap.add_argument("--count-every-step", action="store_true", help="count the valid bits of the gathered masks every step, not only after the last")
     ap.add_argument("--one-ctx", action="store_true", help="headline through one ctx on one stream (the round-2 form) instead of mvk_pipe_* with two contexts")
     ap.add_argument("--pipe-depth", type=int, default=2, help="contexts (lanes) of the headline's pipe, 2..4")
-    ap.add_argument("--pipe-timeout", type=float, default=180.0, help="N > 1: seconds the pipelined exchange loop may take before the "
+    ap.add_argument("--pipe-timeout", type=float, default=90.0, help="N > 1: seconds the pipelined exchange loop may take before the "
                     "line is printed from the one-ctx loop's figures instead (a guard for a path no single-GPU box can rehearse)")
     ap.add_argument("--slots", type=int, default=4, help="exchange buffer sets: how many steps the host may run ahead of the exchange")
     ap.add_argument("--cold-steps", type=int, default=20, help="N = 1: timed steps of the from-cold pass before the pre-warm (0: skip)")
