@@ -155,7 +155,7 @@ def margins_agree(model, states, got, ref):
     the reference's FullPivLU of P P^T); near a singular rotor arrangement (all rotors nearly in line) that solve
     carries cond(A)^2 roundings, which two correct fp64 evaluations in different operation order (the GPU contracts to
     FMAs, the oracle is built -ffp-contract=off) do not share: measured 0.2 - 0.35 u cond(A)^2 on the two such states the
-    fuzz soak found in 2.2 M (profiles/soak_fuzz.py, profiles/r03/soak_fuzz.txt: thrusts of 4e4 and 3.8e5 N, cond(A) 1e6
+    fuzz soak found in 2.9 M (profiles/soak_fuzz.py, profiles/r03/soak_fuzz.txt: thrusts of 4e4 and 3.8e5 N, cond(A) 1e6
     and 2e6).  A state that misses the 1e-5 bar is therefore held to 8 u cond(A)^2 instead, cond(A) from the independent
     NumPy restatement (oracle/np_vspec.py).  Such states are unstable by orders of magnitude: no flag is in question."""
     import os, sys
